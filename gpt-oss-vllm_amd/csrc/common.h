@@ -1,0 +1,59 @@
+// Shared host/device helpers of libmoe355 (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "m355.h"
+
+namespace m355 {
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+
+// NF4 code book, patches/streaming_unsloth_bnb.py:101-106 of the reference.
+#define M355_NF4_TABLE                                                                                   \
+    {-1.0f, -0.6961928009986877f, -0.5250730514526367f, -0.39491748809814453f, -0.28444138169288635f,    \
+     -0.18477343022823334f, -0.09105003625154495f, 0.0f, 0.07958029955625534f, 0.16093020141124725f,     \
+     0.24611230194568634f, 0.33791524171829224f, 0.44070982933044434f, 0.5626170039176941f,              \
+     0.7229568362236023f, 1.0f}
+
+// ---- error reporting (thread-local message, integer status) ----
+char* error_buffer();
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+inline int hip_status(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    return fail((int)e, "%s: %s", what, hipGetErrorString(e));
+}
+#define M355_LAUNCH_CHECK(what)                                      \
+    do {                                                             \
+        hipError_t e__ = hipGetLastError();                          \
+        if (e__ != hipSuccess) return m355::hip_status(e__, what);   \
+    } while (0)
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+// ---- device helpers ----
+// Reinterpret a dword as two fp16.  Always go through this by-value helper: __builtin_bit_cast applied
+// directly to an indexed vector element (v[j] with an unrolled loop index) was seen to read element 0
+// for every j with hipcc 7.2.
+__device__ __forceinline__ half2_t as_half2(uint32_t v) { return __builtin_bit_cast(half2_t, v); }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+}  // namespace m355

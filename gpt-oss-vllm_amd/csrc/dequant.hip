@@ -1,0 +1,121 @@
+// Standalone NF4 -> fp16 dequantizer and the checkpoint-order -> tile-order repack.
+// Both are pure byte movers bound by HBM: 0.515625 B read + 2 B written per weight for the
+// dequantizer, one read and one write of every byte for the repack.
+#include "common.h"
+
+namespace m355 {
+
+// Each work item turns 4 packed bytes (8 weights) into 16 bytes of fp16, so a wave reads 256
+// contiguous bytes and writes 1 KiB contiguous per step.  The code book is looked up per byte in
+// LDS as a float2 (low-nibble code, high-nibble code); products are taken in fp32 and rounded to
+// nearest even, which reproduces the reference bit for bit.
+__global__ __launch_bounds__(256) void nf4_dequant_kernel(const uint32_t* __restrict__ q,
+                                                          const float* __restrict__ absmax, int64_t n_items,
+                                                          int blocksize, u32x4_t* __restrict__ out) {
+    __shared__ float2 lut[256];
+    {
+        const float tab[16] = M355_NF4_TABLE;
+        const int b = threadIdx.x;
+        lut[b] = make_float2(tab[b & 15], tab[b >> 4]);
+    }
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    constexpr int U = 4;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; base < n_items; base += stride * U) {
+        uint32_t pk[U];
+        float am[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t it = base + u * stride;
+            const bool ok = it < n_items;
+            pk[u] = ok ? __builtin_nontemporal_load(q + it) : 0u;
+            am[u] = ok ? absmax[(it * 8) / blocksize] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t it = base + u * stride;
+            if (it >= n_items) continue;
+            u32x4_t o;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float2 c = lut[(pk[u] >> (8 * j)) & 0xffu];
+                const half2_t h = {(half_t)(c.x * am[u]), (half_t)(c.y * am[u])};
+                o[j] = __builtin_bit_cast(uint32_t, h);
+            }
+            __builtin_nontemporal_store(o, out + it);
+        }
+    }
+}
+
+// One thread per 8-byte granule of the tiled image.
+__global__ __launch_bounds__(256) void repack_q_kernel(const uint2* __restrict__ q, int rows, int cols,
+                                                       uint2* __restrict__ qt) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)rows * cols / 16;
+    if (o >= total) return;
+    const int NB = cols / 64, P = rows / 32;
+    const int half = (int)(o & 1);
+    const int lane = (int)((o >> 1) & 63);
+    const int64_t pb = o >> 7;
+    const int b = (int)(pb % NB), p = (int)(pb / NB);
+    const int r = lane & 15, g = lane >> 4;
+    const int row = 16 * (p + half * P) + r;
+    const int64_t src_byte = ((int64_t)row * cols + 64 * b + 16 * g) / 2;
+    qt[o] = q[src_byte / 8];
+}
+
+__global__ __launch_bounds__(256) void repack_absmax_kernel(const float* __restrict__ a, int rows, int cols,
+                                                            float* __restrict__ at) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int NB = cols / 64, P = rows / 32;
+    const int64_t total = (int64_t)rows * NB;
+    if (o >= total) return;
+    const int i = (int)(o & 3);
+    int64_t t = o >> 2;
+    const int b = (int)(t % NB);
+    t /= NB;
+    const int g = (int)(t & 3);
+    t >>= 2;
+    const int half = (int)(t & 1);
+    const int p = (int)(t >> 1);
+    const int row = 16 * (p + half * P) + 4 * g + i;
+    at[o] = a[(int64_t)row * NB + b];
+}
+
+}  // namespace m355
+
+using namespace m355;
+
+extern "C" int m355_nf4_dequant(const uint8_t* q, const float* absmax, int64_t n, int blocksize, void* out_f16,
+                                m355_stream_t stream) {
+    if (!q || !absmax || !out_f16) return fail(-1, "m355_nf4_dequant: null pointer");
+    if (n <= 0 || blocksize <= 0 || (blocksize % 8) || (n % blocksize))
+        return fail(-2, "m355_nf4_dequant: need n %% blocksize == 0 and blocksize %% 8 == 0 (n=%lld, blocksize=%d)",
+                    (long long)n, blocksize);
+    if (!aligned(q, 4) || !aligned(out_f16, 16)) return fail(-3, "m355_nf4_dequant: q must be 4-byte and out 16-byte aligned");
+    const int64_t items = n / 8;
+    int64_t blocks = (items + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    nf4_dequant_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const uint32_t*>(q), absmax, items, blocksize, reinterpret_cast<u32x4_t*>(out_f16));
+    M355_LAUNCH_CHECK("m355_nf4_dequant");
+    return 0;
+}
+
+extern "C" int m355_repack_nf4(const uint8_t* q, const float* absmax, int rows, int cols, uint8_t* q_tiled,
+                               float* absmax_tiled, m355_stream_t stream) {
+    if (!q || !absmax || !q_tiled || !absmax_tiled) return fail(-1, "m355_repack_nf4: null pointer");
+    if (rows <= 0 || cols <= 0 || (rows % 32) || (cols % 64))
+        return fail(-2, "m355_repack_nf4: need rows %% 32 == 0 and cols %% 64 == 0 (rows=%d, cols=%d)", rows, cols);
+    if (!aligned(q, 8) || !aligned(q_tiled, 16)) return fail(-3, "m355_repack_nf4: q 8-byte, q_tiled 16-byte aligned");
+    if (q == q_tiled || absmax == absmax_tiled) return fail(-4, "m355_repack_nf4: in-place repack is not supported");
+    const int64_t granules = (int64_t)rows * cols / 16;
+    repack_q_kernel<<<dim3((unsigned)((granules + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const uint2*>(q), rows, cols, reinterpret_cast<uint2*>(q_tiled));
+    M355_LAUNCH_CHECK("m355_repack_nf4(q)");
+    const int64_t na = (int64_t)rows * (cols / 64);
+    repack_absmax_kernel<<<dim3((unsigned)((na + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(absmax, rows, cols,
+                                                                                                   absmax_tiled);
+    M355_LAUNCH_CHECK("m355_repack_nf4(absmax)");
+    return 0;
+}

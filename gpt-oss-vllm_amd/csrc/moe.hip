@@ -1,0 +1,377 @@
+// Fused NF4-dequant grouped GEMM for the MoE experts, decode shapes (few tokens per expert).
+//
+// HBM-bound: every call streams the packed 4-bit blocks of the experts that were hit exactly once
+// (0.5 B per weight) plus their per-64 absmax; the arithmetic runs on the matrix cores with the
+// tokens on the 16-wide N side of v_mfma_f32_16x16x32_f16, so 1..16 tokens per expert cost the same.
+//
+// Pipeline of one forward (all on the caller's stream):
+//   moe_route_kernel      groups the (token, k) pairs by local expert (counts, offsets, sorted list)
+//   moe_gemm_kernel<0>    h[pair] = silu(W13 x)[:FF] * (W13 x)[FF:]            (gate/up fused epilogue)
+//   moe_gemm_kernel<1>    y[pair] = W2 h[pair]
+//   moe_combine_kernel    out[t]  = sum_k w[t][k] * y[pair(t,k)]
+//
+// Weight tile order (written by m355_repack_nf4): for row-tile pair p and 64-column block b, one
+// contiguous KiB; lane 16g+r owns 16 bytes = 8 bytes of row 16p+r (columns 64b+16g..+15) and 8 bytes of the
+// partner row 16(p+P)+r, same columns.  One global_load_dwordx4 per lane therefore brings the A operands of
+// four MFMAs (two K-steps for each of the two row tiles), every wave-load is 1 KiB contiguous, and because
+// the two K-steps of a tile stay inside one 64-column block the block's absmax can be applied to the
+// 16x16 partial product afterwards (4 FMAs per lane) instead of to every weight.
+//
+// Dequantisation: a byte holds two codes; a 256-entry table of packed half2 (code[lo], code[hi]) is
+// replicated 32x in LDS (entry address = (byte*32 + lane%32)*4) so a wave's lookups never collide on a bank.
+// The code values are fp16-rounded NF4 entries; scales stay fp32.
+#include "common.h"
+
+namespace m355 {
+
+constexpr int MOE_THREADS = 512;  // 8 waves = 2 row-tile pairs x 4 K-parts
+constexpr int MOE_PAIRS = 2;
+constexpr int MOE_KPARTS = 4;
+constexpr int MOE_CHUNK = 12;     // 64-column blocks (1 KiB wave-loads) a wave keeps in flight
+constexpr int LUT_BYTES = 256 * 32 * 4;
+constexpr int RED_BYTES = MOE_PAIRS * (MOE_KPARTS - 1) * 64 * 8 * 4;
+constexpr int XS_PAD = 16;        // bytes of padding per staged activation row
+constexpr int MOE_MAX_MT = 16;
+
+__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct MoeWorkspace {
+    int32_t* n_active;   // [1]
+    int32_t* offsets;    // [E_local + 1]
+    int32_t* active;     // [E_local]
+    int32_t* sorted;     // [P]   sorted position -> pair index (t*k + kk)
+    int32_t* inv;        // [P]   pair index -> sorted position, -1 if the expert is not local
+    half_t* h;           // [P][FF]
+    half_t* y;           // [P][H]
+    size_t bytes;
+};
+
+__host__ inline MoeWorkspace carve_workspace(void* base, int T, int k, int H, int FF, int E_local) {
+    const size_t P = (size_t)T * k;
+    size_t off = 0;
+    char* b = reinterpret_cast<char*>(base);
+    MoeWorkspace w;
+    w.n_active = reinterpret_cast<int32_t*>(b + off); off = align_up(off + 4, 256);
+    w.offsets = reinterpret_cast<int32_t*>(b + off);  off = align_up(off + 4 * (size_t)(E_local + 1), 256);
+    w.active = reinterpret_cast<int32_t*>(b + off);   off = align_up(off + 4 * (size_t)E_local, 256);
+    w.sorted = reinterpret_cast<int32_t*>(b + off);   off = align_up(off + 4 * P, 256);
+    w.inv = reinterpret_cast<int32_t*>(b + off);      off = align_up(off + 4 * P, 256);
+    w.h = reinterpret_cast<half_t*>(b + off);         off = align_up(off + 2 * P * FF, 256);
+    w.y = reinterpret_cast<half_t*>(b + off);         off = align_up(off + 2 * P * H, 256);
+    w.bytes = off;
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Routing: one workgroup buckets the pairs by local expert.
+// ------------------------------------------------------------------------------------------------
+constexpr int ROUTE_THREADS = 1024;
+constexpr int ROUTE_MAX_E = 1024;
+
+__global__ __launch_bounds__(ROUTE_THREADS) void moe_route_kernel(const int32_t* __restrict__ ids, int P, int E_local,
+                                                                  int e_first, int32_t* __restrict__ n_active,
+                                                                  int32_t* __restrict__ offsets,
+                                                                  int32_t* __restrict__ active,
+                                                                  int32_t* __restrict__ sorted,
+                                                                  int32_t* __restrict__ inv) {
+    __shared__ int cnt[ROUTE_MAX_E];
+    __shared__ int cur[ROUTE_MAX_E];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < E_local; e += ROUTE_THREADS) cnt[e] = 0;
+    __syncthreads();
+    for (int p = tid; p < P; p += ROUTE_THREADS) {
+        const int e = ids[p] - e_first;
+        if (e >= 0 && e < E_local) atomicAdd(&cnt[e], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0, na = 0;
+        for (int e = 0; e < E_local; e++) {
+            offsets[e] = run;
+            cur[e] = run;
+            if (cnt[e] > 0) active[na++] = e;
+            run += cnt[e];
+        }
+        offsets[E_local] = run;
+        *n_active = na;
+    }
+    __syncthreads();
+    for (int p = tid; p < P; p += ROUTE_THREADS) {
+        const int e = ids[p] - e_first;
+        int pos = -1;
+        if (e >= 0 && e < E_local) {
+            pos = atomicAdd(&cur[e], 1);
+            sorted[pos] = p;
+        }
+        inv[p] = pos;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused dequant GEMM
+// ------------------------------------------------------------------------------------------------
+// Broadcast lane (16*row + I)'s value to the 16 lanes of its row.
+template <int I>
+__device__ __forceinline__ float row_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + I, 0xf, 0xf, false));
+}
+
+__device__ __forceinline__ half8_t lut4(const uint32_t* lut_lane, uint32_t d) {
+    u32x4_t r;
+    r[0] = lut_lane[(d & 0xffu) * 32];
+    r[1] = lut_lane[((d >> 8) & 0xffu) * 32];
+    r[2] = lut_lane[((d >> 16) & 0xffu) * 32];
+    r[3] = lut_lane[(d >> 24) * 32];
+    return __builtin_bit_cast(half8_t, r);
+}
+
+// MODE 0: xin = x [T][K] gathered by token, out = h [P][R/2] with the silu(gate)*up epilogue.
+// MODE 1: xin = h [P][K] rows taken in sorted order, out = y [P][R].
+// W is [R][K] per expert, in tile order.  grid = (ceil(R/32 / 2), slots); slot s serves active[s].
+template <int MODE>
+__global__ __launch_bounds__(MOE_THREADS) void moe_gemm_kernel(const half_t* __restrict__ xin,
+                                                               const uint8_t* __restrict__ wq,
+                                                               const float* __restrict__ wam,
+                                                               const int32_t* __restrict__ n_active,
+                                                               const int32_t* __restrict__ offsets,
+                                                               const int32_t* __restrict__ active,
+                                                               const int32_t* __restrict__ sorted, int K, int R,
+                                                               int k_top, int mt_rows, half_t* __restrict__ outp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int slot = blockIdx.y;
+    if (slot >= *n_active) return;
+    const int e = active[slot];
+    const int pos0 = offsets[e];
+    const int M = offsets[e + 1] - pos0;
+
+    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
+    float* red = reinterpret_cast<float*>(smem + LUT_BYTES);
+    unsigned char* xs = smem + LUT_BYTES + RED_BYTES;
+    const int XS = K * 2 + XS_PAD;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = wave >> 2, q = wave & 3;
+    const int NB = K / 64;
+    const int NP = R / 32;
+    const int p = blockIdx.x * MOE_PAIRS + pl;
+    const bool live = p < NP;
+    const int pc = live ? p : NP - 1;   // idle waves still run the loads on a valid tile (results dropped)
+    const int BQ = (NB + MOE_KPARTS - 1) / MOE_KPARTS;
+    const int bq0 = min(q * BQ, NB), bq1 = min(bq0 + BQ, NB);
+    const int n = lane & 15, g = lane >> 4;
+
+    const u32x4_t* wtile = reinterpret_cast<const u32x4_t*>(wq + (size_t)e * ((size_t)R * K / 2)) + (size_t)pc * NB * 64 + lane;
+    const float4_t* amA = reinterpret_cast<const float4_t*>(wam + (size_t)e * ((size_t)R * NB)) + ((size_t)(pc * 2 + 0) * 4 + g) * NB;
+    const float4_t* amB = reinterpret_cast<const float4_t*>(wam + (size_t)e * ((size_t)R * NB)) + ((size_t)(pc * 2 + 1) * 4 + g) * NB;
+
+    u32x4_t wreg[MOE_CHUNK];
+    float4_t sA, sB;
+    auto load_chunk = [&](int cb) {
+#pragma unroll
+        for (int i = 0; i < MOE_CHUNK; i++) {
+            const int b = min(cb + i, NB - 1);
+            wreg[i] = __builtin_nontemporal_load(wtile + (size_t)b * 64);
+        }
+        const int bs = min(cb + n, NB - 1);
+        sA = amA[bs];
+        sB = amB[bs];
+    };
+    load_chunk(bq0);   // weights are on their way while the table and the activations are set up
+    bool preloaded = true;
+
+    // code table: thread t fills 16 of the 32 replicas of byte value t/2
+    {
+        const float tab[16] = M355_NF4_TABLE;
+        const int bv = tid >> 1;
+        const half2_t hv = {(half_t)tab[bv & 15], (half_t)tab[bv >> 4]};
+        const uint32_t v = __builtin_bit_cast(uint32_t, hv);
+#pragma unroll
+        for (int i = 0; i < 16; i++) lut[bv * 32 + (tid & 1) * 16 + i] = v;
+    }
+    const uint32_t* lut_lane = lut + (lane & 31);
+
+    for (int m0 = 0; m0 < M; m0 += mt_rows) {
+        const int mt = min(mt_rows, M - m0);
+        // stage the activation rows of this token tile
+        {
+            const int cpr = K / 8;   // 16-byte pieces per row
+            for (int idx = tid; idx < mt * cpr; idx += MOE_THREADS) {
+                const int row = idx / cpr, c = idx - row * cpr;
+                const int pos = pos0 + m0 + row;
+                const int64_t src_row = (MODE == 0) ? (int64_t)(sorted[pos] / k_top) : (int64_t)pos;
+                const u32x4_t v = reinterpret_cast<const u32x4_t*>(xin + src_row * K)[c];
+                *reinterpret_cast<u32x4_t*>(xs + row * XS + c * 16) = v;
+            }
+        }
+        __syncthreads();
+
+        float4_t accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+        const unsigned char* xrow = xs + min(n, mt - 1) * XS + g * 32;
+        for (int cb = bq0; cb < bq1; cb += MOE_CHUNK) {
+            if (!preloaded) load_chunk(cb);
+            preloaded = false;
+#define M355_BLOCK(I)                                                                                       \
+    if (cb + I < bq1) {                                                                                     \
+        const unsigned char* xb = xrow + (cb + I) * 128;                                                    \
+        const half8_t b0 = *reinterpret_cast<const half8_t*>(xb);                                           \
+        const half8_t b1 = *reinterpret_cast<const half8_t*>(xb + 16);                                      \
+        const u32x4_t wv = wreg[I];                                                                         \
+        const float4_t z = {0.f, 0.f, 0.f, 0.f};                                                            \
+        float4_t pA = __builtin_amdgcn_mfma_f32_16x16x32_f16(lut4(lut_lane, wv[0]), b0, z, 0, 0, 0);        \
+        float4_t pB = __builtin_amdgcn_mfma_f32_16x16x32_f16(lut4(lut_lane, wv[2]), b0, z, 0, 0, 0);        \
+        pA = __builtin_amdgcn_mfma_f32_16x16x32_f16(lut4(lut_lane, wv[1]), b1, pA, 0, 0, 0);                \
+        pB = __builtin_amdgcn_mfma_f32_16x16x32_f16(lut4(lut_lane, wv[3]), b1, pB, 0, 0, 0);                \
+        _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                     \
+            accA[r] += row_bcast<I>(sA[r]) * pA[r];                                                         \
+            accB[r] += row_bcast<I>(sB[r]) * pB[r];                                                         \
+        }                                                                                                   \
+    }
+            M355_BLOCK(0) M355_BLOCK(1) M355_BLOCK(2) M355_BLOCK(3) M355_BLOCK(4) M355_BLOCK(5)
+            M355_BLOCK(6) M355_BLOCK(7) M355_BLOCK(8) M355_BLOCK(9) M355_BLOCK(10) M355_BLOCK(11)
+#undef M355_BLOCK
+        }
+
+        // sum the K-parts: parts 1..3 park their tiles in LDS, part 0 adds them and writes the result
+        if (q > 0) {
+            float4_t* dst = reinterpret_cast<float4_t*>(red) + ((size_t)(pl * (MOE_KPARTS - 1) + (q - 1)) * 64 + lane) * 2;
+            dst[0] = accA;
+            dst[1] = accB;
+        }
+        __syncthreads();
+        if (q == 0 && live) {
+#pragma unroll
+            for (int qq = 0; qq < MOE_KPARTS - 1; qq++) {
+                const float4_t* src = reinterpret_cast<const float4_t*>(red) + ((size_t)(pl * (MOE_KPARTS - 1) + qq) * 64 + lane) * 2;
+                accA += src[0];
+                accB += src[1];
+            }
+            if (n < mt) {
+                const int64_t orow = pos0 + m0 + n;
+                if (MODE == 0) {
+                    half4_t hv;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float gt = (float)(half_t)accA[r];   // gate and up leave the GEMM as fp16
+                        const float up = (float)(half_t)accB[r];
+                        const half_t s = (half_t)(gt / (1.0f + expf(-gt)));
+                        hv[r] = (half_t)((float)s * up);
+                    }
+                    *reinterpret_cast<half4_t*>(outp + orow * (R / 2) + 16 * p + 4 * g) = hv;
+                } else {
+                    half4_t ya, yb;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { ya[r] = (half_t)accA[r]; yb[r] = (half_t)accB[r]; }
+                    *reinterpret_cast<half4_t*>(outp + orow * R + 16 * p + 4 * g) = ya;
+                    *reinterpret_cast<half4_t*>(outp + orow * R + 16 * (p + NP) + 4 * g) = yb;
+                }
+            }
+        }
+        __syncthreads();   // red and xs are reused by the next token tile
+    }
+}
+
+// out[t][c] = sum over the token's local pairs, in k order.  FP16 mode rounds as the reference's fp16
+// tensors do: w -> fp16, product -> fp16, running sum -> fp16.
+__global__ __launch_bounds__(256) void moe_combine_kernel(const half_t* __restrict__ y, const int32_t* __restrict__ inv,
+                                                          const float* __restrict__ w, int H, int k_top, int fp16_mode,
+                                                          half_t* __restrict__ out) {
+    const int t = blockIdx.x;
+    const int chunks = H / 8;
+    for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = 0.f;
+        for (int kk = 0; kk < k_top; kk++) {
+            const int pos = inv[t * k_top + kk];
+            if (pos < 0) continue;
+            const half8_t yv = reinterpret_cast<const half8_t*>(y + (int64_t)pos * H)[c];
+            const float wf = w[t * k_top + kk];
+            if (fp16_mode) {
+                const float w16 = (float)(half_t)wf;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float prod = (float)(half_t)(w16 * (float)yv[j]);
+                    acc[j] = (float)(half_t)(acc[j] + prod);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[j] += wf * (float)yv[j];
+            }
+        }
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = (half_t)acc[j];
+        reinterpret_cast<half8_t*>(out + (int64_t)t * H)[c] = o;
+    }
+}
+
+static int gemm_lds_bytes(int K, int mt_rows) { return LUT_BYTES + RED_BYTES + mt_rows * (K * 2 + XS_PAD); }
+
+}  // namespace m355
+
+using namespace m355;
+
+extern "C" size_t m355_moe_workspace_bytes(int T, int k, int H, int FF, int E_local) {
+    if (T < 0 || k <= 0 || H <= 0 || FF <= 0 || E_local <= 0) return 0;
+    return carve_workspace(nullptr, T, k, H, FF, E_local).bytes;
+}
+
+extern "C" int m355_moe_nf4_forward(const void* x_f16, int T, const int32_t* ids, const float* w, int k,
+                                    const uint8_t* w13_q, const float* w13_absmax, const uint8_t* w2_q,
+                                    const float* w2_absmax, int E_local, int e_first, int H, int FF, int act_mode,
+                                    int flags, void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream) {
+    if (T == 0) return 0;   // an empty batch has no buffers to check
+    if (!x_f16 || !ids || !w || !w13_q || !w13_absmax || !w2_q || !w2_absmax || !out_f16)
+        return fail(-1, "m355_moe_nf4_forward: null pointer");
+    if (T < 0 || k <= 0 || k > 32 || E_local <= 0 || E_local > ROUTE_MAX_E || H <= 0 || FF <= 0 || (H % 64) || (FF % 64))
+        return fail(-2, "m355_moe_nf4_forward: unsupported shape T=%d k=%d E_local=%d H=%d FF=%d (need H,FF %% 64 == 0, k <= 32, E_local <= %d)",
+                    T, k, E_local, H, FF, ROUTE_MAX_E);
+    if (act_mode != M355_ACT_SILU_CONCAT) return fail(-5, "m355_moe_nf4_forward: act_mode %d not supported", act_mode);
+    if ((int64_t)T * k > (int64_t)1 << 24) return fail(-2, "m355_moe_nf4_forward: T*k too large");
+    const size_t need = m355_moe_workspace_bytes(T, k, H, FF, E_local);
+    if (!workspace || ws_bytes < need) return fail(-6, "m355_moe_nf4_forward: workspace of %zu bytes needed, %zu given", need, ws_bytes);
+    if (!aligned(workspace, 256) || !aligned(x_f16, 16) || !aligned(out_f16, 16) || !aligned(w13_q, 16) || !aligned(w2_q, 16) ||
+        !aligned(w13_absmax, 16) || !aligned(w2_absmax, 16))
+        return fail(-3, "m355_moe_nf4_forward: workspace 256-byte, other buffers 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const MoeWorkspace ws = carve_workspace(workspace, T, k, H, FF, E_local);
+    const int P = T * k;
+    const int mt_rows = T < MOE_MAX_MT ? T : MOE_MAX_MT;
+    const int slots = P < E_local ? P : E_local;
+
+    static bool attr_set = false;
+    if (!attr_set) {
+        int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_gemm_kernel<0>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
+        if (rc) return rc;
+        rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_gemm_kernel<1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
+        if (rc) return rc;
+        attr_set = true;
+    }
+    const int lds13 = gemm_lds_bytes(H, mt_rows), lds2 = gemm_lds_bytes(FF, mt_rows);
+    if (lds13 > 160 * 1024 || lds2 > 160 * 1024)
+        return fail(-2, "m355_moe_nf4_forward: H or FF too large for the LDS activation tile (%d / %d bytes)", lds13, lds2);
+
+    moe_route_kernel<<<dim3(1), dim3(ROUTE_THREADS), 0, st>>>(ids, P, E_local, e_first, ws.n_active, ws.offsets, ws.active,
+                                                              ws.sorted, ws.inv);
+    M355_LAUNCH_CHECK("moe_route_kernel");
+    {
+        const int R = 2 * FF, NP = R / 32;
+        moe_gemm_kernel<0><<<dim3((NP + MOE_PAIRS - 1) / MOE_PAIRS, slots), dim3(MOE_THREADS), lds13, st>>>(
+            (const half_t*)x_f16, w13_q, w13_absmax, ws.n_active, ws.offsets, ws.active, ws.sorted, H, R, k, mt_rows, ws.h);
+        M355_LAUNCH_CHECK("moe_gemm_kernel<gate_up>");
+    }
+    {
+        const int R = H, NP = R / 32;
+        moe_gemm_kernel<1><<<dim3((NP + MOE_PAIRS - 1) / MOE_PAIRS, slots), dim3(MOE_THREADS), lds2, st>>>(
+            ws.h, w2_q, w2_absmax, ws.n_active, ws.offsets, ws.active, ws.sorted, FF, R, k, mt_rows, ws.y);
+        M355_LAUNCH_CHECK("moe_gemm_kernel<down>");
+    }
+    moe_combine_kernel<<<dim3(T), dim3(256), 0, st>>>(ws.y, ws.inv, w, H, k, (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0,
+                                                      (half_t*)out_f16);
+    M355_LAUNCH_CHECK("moe_combine_kernel");
+    return 0;
+}

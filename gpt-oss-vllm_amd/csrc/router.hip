@@ -1,0 +1,133 @@
+// Router: fp16 linear (H -> E logits) + top-k + softmax over the selected logits, one workgroup per
+// token.  The dot products are spread over the workgroup's waves (4 experts at a time per wave so
+// each 16-byte piece of x is read once per 4 experts); wave 0 then selects the k largest logits by
+// repeated wave-wide arg-max (value descending, expert id ascending on ties).
+#include "common.h"
+
+namespace m355 {
+
+constexpr int ROUTER_THREADS = 512;
+constexpr int ROUTER_MAX_E = 1024;
+
+// Wave-wide arg-max over (v, idx): larger v wins, on equal v the smaller idx wins.
+__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+// Selects top-k of logit[0..E) (LDS, fp32 values that are exact fp16 numbers); run by one whole wave.
+__device__ __forceinline__ void topk_softmax_wave(float* logit, int E, int k, int32_t* ids_out, float* w_out) {
+    const int lane = threadIdx.x & 63;
+    float myv = 0.f;
+    int myid = 0;
+    for (int j = 0; j < k; j++) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int e = lane; e < E; e += 64) {
+            const float v = logit[e];
+            if (v > bv || (v == bv && e < bi)) { bv = v; bi = e; }   // NaN logits never win
+        }
+        wave_argmax(bv, bi);
+        if (bi == 0x7fffffff) bi = j;   // all remaining are NaN / -inf: fall back to a valid id
+        if (lane == j) { myv = bv; myid = bi; }
+        if (lane == 0 && bi < E) logit[bi] = -INFINITY;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const float mx = __shfl(myv, 0, 64);          // first pick is the largest
+    float p = (lane < k) ? __expf(myv - mx) : 0.f;
+    const float sum = wave_sum(p);
+    if (lane < k) {
+        ids_out[lane] = myid;
+        w_out[lane] = p / sum;
+    }
+}
+
+__global__ __launch_bounds__(ROUTER_THREADS) void router_topk_kernel(const half_t* __restrict__ x,
+                                                                     const half_t* __restrict__ wr,
+                                                                     const half_t* __restrict__ br, int H, int E, int k,
+                                                                     int32_t* __restrict__ ids, float* __restrict__ w,
+                                                                     half_t* __restrict__ logits_out) {
+    __shared__ float logit[ROUTER_MAX_E];
+    const int t = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int NW = ROUTER_THREADS / 64;
+    const int chunks = H / 8;
+    const u32x4_t* xr = reinterpret_cast<const u32x4_t*>(x + (int64_t)t * H);
+    for (int e0 = wave * 4; e0 < E; e0 += NW * 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = lane; c < chunks; c += 64) {
+            const u32x4_t xv = xr[c];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int e = (e0 + i < E) ? e0 + i : E - 1;
+                const u32x4_t wv = reinterpret_cast<const u32x4_t*>(wr + (int64_t)e * H)[c];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[i] = __builtin_amdgcn_fdot2(as_half2(xv[j]), as_half2(wv[j]),
+                                                    acc[i], false);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float s = wave_sum(acc[i]);
+            if (lane == 0 && e0 + i < E) {
+                const float full = s + (br ? (float)br[e0 + i] : 0.f);
+                const half_t l16 = (half_t)full;   // the reference's router output is an fp16 tensor
+                logit[e0 + i] = (float)l16;
+                if (logits_out) logits_out[(int64_t)t * E + e0 + i] = l16;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) topk_softmax_wave(logit, E, k, ids + (int64_t)t * k, w + (int64_t)t * k);
+}
+
+__global__ __launch_bounds__(256) void topk_softmax_kernel(const half_t* __restrict__ logits, int T, int E, int k,
+                                                           int32_t* __restrict__ ids, float* __restrict__ w) {
+    extern __shared__ __attribute__((aligned(16))) float lg[];   // [4][E]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= T) return;
+    float* mine = lg + wave * E;
+    for (int e = lane; e < E; e += 64) mine[e] = (float)logits[(int64_t)t * E + e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    topk_softmax_wave(mine, E, k, ids + (int64_t)t * k, w + (int64_t)t * k);
+}
+
+}  // namespace m355
+
+using namespace m355;
+
+extern "C" int m355_router_topk(const void* x_f16, const void* wr_f16, const void* br_f16, int T, int H, int E, int k,
+                                int32_t* ids, float* w, void* logits_out_f16, m355_stream_t stream) {
+    if (T == 0) return 0;
+    if (!x_f16 || !wr_f16 || !ids || !w) return fail(-1, "m355_router_topk: null pointer");
+    if (T < 0 || H <= 0 || (H % 8) || E <= 0 || E > ROUTER_MAX_E || k <= 0 || k > 32 || k > E)
+        return fail(-2, "m355_router_topk: unsupported shape T=%d H=%d E=%d k=%d (need H %% 8 == 0, E <= %d, k <= min(32,E))",
+                    T, H, E, k, ROUTER_MAX_E);
+    if (!aligned(x_f16, 16) || !aligned(wr_f16, 16)) return fail(-3, "m355_router_topk: x and wr must be 16-byte aligned");
+    if (T == 0) return 0;
+    router_topk_kernel<<<dim3(T), dim3(ROUTER_THREADS), 0, (hipStream_t)stream>>>(
+        (const half_t*)x_f16, (const half_t*)wr_f16, (const half_t*)br_f16, H, E, k, ids, w, (half_t*)logits_out_f16);
+    M355_LAUNCH_CHECK("m355_router_topk");
+    return 0;
+}
+
+extern "C" int m355_topk_softmax(const void* logits_f16, int T, int E, int k, int32_t* ids, float* w,
+                                 m355_stream_t stream) {
+    if (T == 0) return 0;
+    if (!logits_f16 || !ids || !w) return fail(-1, "m355_topk_softmax: null pointer");
+    if (T < 0 || E <= 0 || E > ROUTER_MAX_E || k <= 0 || k > 32 || k > E)
+        return fail(-2, "m355_topk_softmax: unsupported shape T=%d E=%d k=%d", T, E, k);
+    if (T == 0) return 0;
+    topk_softmax_kernel<<<dim3((T + 3) / 4), dim3(256), 4 * E * sizeof(float), (hipStream_t)stream>>>(
+        (const half_t*)logits_f16, T, E, k, ids, w);
+    M355_LAUNCH_CHECK("m355_topk_softmax");
+    return 0;
+}

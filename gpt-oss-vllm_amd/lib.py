@@ -1,0 +1,179 @@
+"""ctypes binding of libmoe355.so (the C ABI declared in include/m355.h) for torch tensors.
+
+torch is used only for device memory and the current HIP stream.  There is no CPU or eager
+fallback: if the shared library is missing, or a tensor is not on a GPU, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmoe355.so")
+
+ACT_SILU_CONCAT = 0
+FLAG_FP16_COMBINE = 1
+
+# every symbol include/m355.h declares
+EXPORTS = (
+    "m355_version", "m355_last_error", "m355_nf4_dequant", "m355_repack_nf4", "m355_router_topk",
+    "m355_topk_softmax", "m355_moe_nf4_forward", "m355_moe_workspace_bytes", "m355_paged_attn_decode",
+    "m355_paged_attn_workspace_bytes",
+)
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class Mi355LibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load libmoe355.so (built by `make -C gpt-oss-vllm_amd/csrc` or __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Mi355LibraryError(
+            f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}`; "
+            "this package has no fallback path")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+    L.m355_version.restype = i32
+    L.m355_last_error.restype = ctypes.c_char_p
+    L.m355_nf4_dequant.argtypes = [vp, vp, i64, i32, vp, vp]
+    L.m355_repack_nf4.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    L.m355_router_topk.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.m355_topk_softmax.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    L.m355_moe_nf4_forward.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
+                                       vp, sz, vp, vp]
+    L.m355_moe_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
+    L.m355_moe_workspace_bytes.restype = sz
+    L.m355_paged_attn_decode.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp, vp]
+    L.m355_paged_attn_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.m355_paged_attn_workspace_bytes.restype = sz
+    for fn in ("m355_nf4_dequant", "m355_repack_nf4", "m355_router_topk", "m355_topk_softmax",
+               "m355_moe_nf4_forward", "m355_paged_attn_decode"):
+        getattr(L, fn).restype = i32
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise Mi355LibraryError(f"{what} failed ({rc}): {load().m355_last_error().decode()}")
+
+
+def _dev(t: torch.Tensor, dtype: torch.dtype, name: str) -> int:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise Mi355LibraryError(f"{name} must be a GPU tensor; this path has no CPU implementation")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def version() -> int:
+    return int(load().m355_version())
+
+
+def nf4_dequant(q: torch.Tensor, absmax: torch.Tensor, blocksize: int = 64, out: Optional[torch.Tensor] = None):
+    """Packed NF4 (uint8, checkpoint order) + fp32 absmax -> flat fp16.  m355_nf4_dequant."""
+    n = q.numel() * 2
+    if out is None:
+        out = torch.empty(n, dtype=torch.float16, device=q.device)
+    if absmax.numel() * blocksize != n:
+        raise ValueError(f"absmax has {absmax.numel()} entries, expected {n // blocksize}")
+    _check(load().m355_nf4_dequant(_dev(q, torch.uint8, "q"), _dev(absmax, torch.float32, "absmax"), n, blocksize,
+                                   _dev(out, torch.float16, "out"), _stream()), "m355_nf4_dequant")
+    return out
+
+
+def repack_nf4(q: torch.Tensor, absmax: torch.Tensor, rows: int, cols: int):
+    """One expert matrix, checkpoint order -> tile order.  m355_repack_nf4."""
+    if q.numel() * 2 != rows * cols or absmax.numel() * 64 != rows * cols:
+        raise ValueError("repack_nf4: sizes do not match rows*cols")
+    qt = torch.empty_like(q)
+    at = torch.empty_like(absmax)
+    _check(load().m355_repack_nf4(_dev(q, torch.uint8, "q"), _dev(absmax, torch.float32, "absmax"), rows, cols,
+                                  _dev(qt, torch.uint8, "q_tiled"), _dev(at, torch.float32, "absmax_tiled"), _stream()),
+           "m355_repack_nf4")
+    return qt, at
+
+
+def router_topk(x: torch.Tensor, wr: torch.Tensor, br: Optional[torch.Tensor], k: int, want_logits: bool = False):
+    """fp16 router linear + top-k + softmax.  Returns (ids int32 [T,k], w fp32 [T,k][, logits fp16 [T,E]])."""
+    T, H = x.shape
+    E = wr.shape[0]
+    ids = torch.empty((T, k), dtype=torch.int32, device=x.device)
+    w = torch.empty((T, k), dtype=torch.float32, device=x.device)
+    logits = torch.empty((T, E), dtype=torch.float16, device=x.device) if want_logits else None
+    _check(load().m355_router_topk(_dev(x, torch.float16, "x"), _dev(wr, torch.float16, "wr"),
+                                   None if br is None else _dev(br, torch.float16, "br"), T, H, E, k,
+                                   ids.data_ptr(), w.data_ptr(), None if logits is None else logits.data_ptr(),
+                                   _stream()), "m355_router_topk")
+    return (ids, w, logits) if want_logits else (ids, w)
+
+
+def topk_softmax(logits: torch.Tensor, k: int):
+    T, E = logits.shape
+    ids = torch.empty((T, k), dtype=torch.int32, device=logits.device)
+    w = torch.empty((T, k), dtype=torch.float32, device=logits.device)
+    _check(load().m355_topk_softmax(_dev(logits, torch.float16, "logits"), T, E, k, ids.data_ptr(), w.data_ptr(),
+                                    _stream()), "m355_topk_softmax")
+    return ids, w
+
+
+def moe_workspace_bytes(T: int, k: int, H: int, FF: int, E_local: int) -> int:
+    return int(load().m355_moe_workspace_bytes(T, k, H, FF, E_local))
+
+
+def moe_nf4_forward(x, ids, w, w13_q, w13_absmax, w2_q, w2_absmax, *, E_local: int, e_first: int, H: int, FF: int,
+                    workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                    act_mode: int = ACT_SILU_CONCAT, flags: int = FLAG_FP16_COMBINE):
+    """One MoE layer over this rank's experts (weights in tile order).  m355_moe_nf4_forward."""
+    T, k = ids.shape
+    need = moe_workspace_bytes(T, k, H, FF, E_local)
+    if workspace is None:
+        workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=x.device)
+    if out is None:
+        out = torch.empty((T, H), dtype=torch.float16, device=x.device)
+    _check(load().m355_moe_nf4_forward(
+        _dev(x, torch.float16, "x"), T, _dev(ids, torch.int32, "ids"), _dev(w, torch.float32, "w"), k,
+        _dev(w13_q, torch.uint8, "w13_q"), _dev(w13_absmax, torch.float32, "w13_absmax"),
+        _dev(w2_q, torch.uint8, "w2_q"), _dev(w2_absmax, torch.float32, "w2_absmax"), E_local, e_first, H, FF,
+        act_mode, flags, _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
+        _dev(out, torch.float16, "out"), _stream()), "m355_moe_nf4_forward")
+    return out
+
+
+def paged_attn_workspace_bytes(B: int, Hq: int, D: int, max_ctx: int) -> int:
+    return int(load().m355_paged_attn_workspace_bytes(B, Hq, D, max_ctx))
+
+
+def paged_attn_decode(q, kcache, vcache, block_tables, ctx_lens, *, max_ctx: int, scale: float,
+                      workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """Decode attention over a paged KV cache.  m355_paged_attn_decode."""
+    B, Hq, D = q.shape
+    _, block_size, Hkv, _ = kcache.shape
+    need = paged_attn_workspace_bytes(B, Hq, D, max_ctx)
+    if workspace is None and need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
+    if out is None:
+        out = torch.empty_like(q)
+    _check(load().m355_paged_attn_decode(
+        _dev(q, torch.float16, "q"), _dev(kcache, torch.float16, "kcache"), _dev(vcache, torch.float16, "vcache"),
+        _dev(block_tables, torch.int32, "block_tables"), _dev(ctx_lens, torch.int32, "ctx_lens"), B, Hq, Hkv, D,
+        block_size, block_tables.shape[1], max_ctx, scale,
+        None if workspace is None else _dev(workspace, torch.uint8, "workspace"),
+        0 if workspace is None else workspace.numel(), _dev(out, torch.float16, "out"), _stream()),
+        "m355_paged_attn_decode")
+    return out

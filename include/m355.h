@@ -1,0 +1,112 @@
+/*
+ * libmoe355 -- C ABI of the MI355X (gfx950) NF4 mixture-of-experts decode path.
+ *
+ * Every entry point enqueues HIP kernels on the caller's stream and returns without synchronising.
+ * All buffers are caller-owned DEVICE pointers unless a parameter says "host"; the library keeps no
+ * per-call state, allocates nothing and frees nothing.  Return value: 0 = ok, < 0 = bad argument or
+ * unsupported shape, > 0 = a hipError_t.  m355_last_error() gives the message for the calling thread.
+ * No C++ exception crosses this boundary.
+ *
+ * Each declaration names the interface of the reference (toddllm/gpt-oss-vllm, paths relative to
+ * its root) whose work it takes over.
+ */
+#ifndef M355_H
+#define M355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M355_API __attribute__((visibility("default")))
+
+typedef void* m355_stream_t; /* a hipStream_t (NULL = the default stream) */
+
+/* act_mode of m355_moe_nf4_forward */
+#define M355_ACT_SILU_CONCAT 0 /* h = silu(gate) * up, gate = rows [0,FF), up = rows [FF,2FF) of W13:
+                                  patches/unsloth_to_vllm_converter.py:312-315,
+                                  patches/streaming_unsloth_bnb.py:269-270 */
+/* flags of m355_moe_nf4_forward */
+#define M355_FLAG_FP16_COMBINE 1 /* routing weights rounded to fp16 and out accumulated over k in fp16, in
+                                    k order, as the reference's fp16 tensors do
+                                    (patches/unsloth_to_vllm_converter.py:301,306,321) */
+
+M355_API int m355_version(void);
+M355_API const char* m355_last_error(void);
+
+/*
+ * NF4 packed bytes -> fp16.  q holds n/2 bytes in checkpoint order (element 2i = low nibble of byte
+ * i), absmax one fp32 per `blocksize` elements, out n fp16.  out[i] = fp16_rne(NF4[code_i] * absmax[i /
+ * blocksize]) with the product taken in fp32: bit-identical to
+ * patches/streaming_unsloth_bnb.py:175-222 (dequant_unsloth_expert_cpu, the divisible-blocksize
+ * branch :199-202, which is the one real checkpoints take).
+ * Requires n % blocksize == 0, blocksize % 8 == 0, q/out 16-byte aligned.
+ */
+M355_API int m355_nf4_dequant(const uint8_t* q, const float* absmax, int64_t n, int blocksize,
+                              void* out_f16, m355_stream_t stream);
+
+/*
+ * Repack one expert matrix from checkpoint order into the tile order the fused kernels stream.
+ * W is [rows][cols] NF4, row-major, two elements per byte (low nibble first), absmax [rows*cols/64]
+ * fp32 (already un-double-quantized by the rules of patches/streaming_unsloth_bnb.py:148-173).
+ * Output sizes equal the input sizes: q_tiled rows*cols/2 bytes, absmax_tiled rows*cols/64 floats.
+ * Requires rows % 32 == 0, cols % 64 == 0.  Replaces the re-quantisation the reference performs when it
+ * moves each expert to the GPU (patches/streaming_unsloth_bnb.py:48-65): the original blocks are kept.
+ * Tile order (p = row-tile pair, b = 64-column block, lane = 16*g + r):
+ *   q_tiled[((p*NB + b)*64 + lane)*16 + 0..7 ] = 8 bytes of row 16*p + r,           columns 64b+16g .. +15
+ *   q_tiled[((p*NB + b)*64 + lane)*16 + 8..15] = 8 bytes of row 16*(p + rows/32) + r, same columns
+ *   absmax_tiled[(((p*2 + half)*4 + g)*NB + b)*4 + i] = absmax of row 16*(p + half*rows/32) + 4g + i, block b
+ */
+M355_API int m355_repack_nf4(const uint8_t* q, const float* absmax, int rows, int cols, uint8_t* q_tiled,
+                             float* absmax_tiled, m355_stream_t stream);
+
+/*
+ * Router: logits = fp16(x . wr^T + br), top-k by value (ties -> lower expert id), softmax over the k
+ * selected logits.  x [T][H] fp16, wr [E][H] fp16, br [E] fp16 or NULL, ids [T][k] int32, w [T][k] fp32.
+ * Replaces the fp16 router nn.Linear that patches/monkey_patch_router_fp16.py:6-17 forces, plus
+ * torch.topk + softmax of patches/unsloth_to_vllm_converter.py:291-292.  E <= 1024, k <= 32, H % 8 == 0.
+ * logits_out: optional [T][E] fp16.
+ */
+M355_API int m355_router_topk(const void* x_f16, const void* wr_f16, const void* br_f16, int T, int H, int E,
+                              int k, int32_t* ids, float* w, void* logits_out_f16, m355_stream_t stream);
+
+/* Same selection on logits the caller already has ([T][E] fp16): the FusedMoE.apply(router_logits=...) form. */
+M355_API int m355_topk_softmax(const void* logits_f16, int T, int E, int k, int32_t* ids, float* w,
+                               m355_stream_t stream);
+
+/*
+ * One MoE layer on this rank's experts: out[t] = sum_k w[t][k] * W2_e( act(W13_e x[t]) ), e = ids[t][k],
+ * over the pairs whose expert lies in [e_first, e_first + E_local); other pairs contribute nothing
+ * (another rank owns them).  x [T][H] fp16, ids [T][k] int32 (global expert ids), w [T][k] fp32,
+ * w13_q [E_local][2FF*H/2] and w2_q [E_local][H*FF/2] in m355_repack_nf4 tile order (W13 is [2FF][H], W2 is
+ * [H][FF]), their absmax in tile order, out [T][H] fp16.  blocksize is fixed at 64.
+ * This is FusedMoE's quant_method.apply for the plug-in that patches/bnb_moe_4bit.py:22-48 declares, with
+ * the forward semantics of patches/unsloth_to_vllm_converter.py:282-325.
+ * Requires H % 64 == 0, FF % 64 == 0, k <= 32; workspace >= m355_moe_workspace_bytes(...), 256-byte aligned.
+ */
+M355_API int m355_moe_nf4_forward(const void* x_f16, int T, const int32_t* ids, const float* w, int k,
+                                  const uint8_t* w13_q, const float* w13_absmax, const uint8_t* w2_q,
+                                  const float* w2_absmax, int E_local, int e_first, int H, int FF, int act_mode,
+                                  int flags, void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream);
+M355_API size_t m355_moe_workspace_bytes(int T, int k, int H, int FF, int E_local);
+
+/*
+ * Decode attention over a paged KV cache: one query token per sequence, grouped-query heads, scores in
+ * fp32, no sinks and no sliding window -- the attention the reference is left with after
+ * patches/patch_3_disable_sinks.py:36-38 and patches/patch_2_force_fa2.py (FlashAttention-2 paged decode).
+ * q [B][Hq][D] fp16, kcache/vcache [num_blocks][block_size][Hkv][D] fp16, block_tables [B][max_blocks] int32,
+ * ctx_lens [B] int32 (cached tokens including the current one), out [B][Hq][D] fp16.
+ * Requires D == 64, Hq / Hkv == 8.  workspace >= m355_paged_attn_workspace_bytes(...) (may be NULL when that is 0).
+ */
+M355_API int m355_paged_attn_decode(const void* q_f16, const void* kcache_f16, const void* vcache_f16,
+                                    const int32_t* block_tables, const int32_t* ctx_lens, int B, int Hq, int Hkv,
+                                    int D, int block_size, int max_blocks, int max_ctx, float scale,
+                                    void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream);
+M355_API size_t m355_paged_attn_workspace_bytes(int B, int Hq, int D, int max_ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* M355_H */

@@ -1,0 +1,34 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def ref():
+    from oracle import ref as _ref
+    _ref.build()
+    return _ref
+
+
+@pytest.fixture(scope="session")
+def m355():
+    import gpt_oss_vllm_amd  # noqa: F401
+    from gpt_oss_vllm_amd import lib
+    return lib
+
+
+@pytest.fixture(scope="session")
+def cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU is visible")
+    return torch.device("cuda:0")

@@ -1,0 +1,233 @@
+"""GPU parity: every call goes through the C ABI (libmoe355.so) and is checked against the CPU oracle
+and the committed golden outputs of the reference.  Run on the GPU box with -m gpu."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+# Tolerance for fp16 GEMM outputs against the reference / oracle (fp32 accumulation in a different order,
+# codes rounded to fp16 before the matrix product): |d| <= 2e-3 * max|y| + 1e-5.
+RTOL_MAX, ATOL = 2e-3, 1e-5
+
+
+def _close(got, want, rtol=RTOL_MAX, atol=ATOL):
+    got = np.asarray(got, dtype=np.float32)
+    want = np.asarray(want, dtype=np.float32)
+    lim = rtol * np.abs(want).max() + atol
+    err = np.abs(got - want).max()
+    assert err <= lim, f"max |d| {err} > {lim}"
+    return err
+
+
+def _to_dev(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def tiled_layer(m355, layer, E, H, FF, cuda):
+    """Upload checkpoint-order experts and repack them on the GPU into tile order."""
+    w13_q = torch.empty((E, FF * H), dtype=torch.uint8, device=cuda)
+    w13_a = torch.empty((E, 2 * FF * H // 64), dtype=torch.float32, device=cuda)
+    w2_q = torch.empty((E, H * FF // 2), dtype=torch.uint8, device=cuda)
+    w2_a = torch.empty((E, H * FF // 64), dtype=torch.float32, device=cuda)
+    for e in range(E):
+        q, a = m355.repack_nf4(_to_dev(layer["w13_q"][e], cuda), _to_dev(layer["w13_absmax"][e], cuda), 2 * FF, H)
+        w13_q[e], w13_a[e] = q, a
+        q, a = m355.repack_nf4(_to_dev(layer["w2_q"][e], cuda), _to_dev(layer["w2_absmax"][e], cuda), H, FF)
+        w2_q[e], w2_a[e] = q, a
+    return w13_q, w13_a, w2_q, w2_a
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["gate_up_nested_mean", "down_nested_mean", "down_nested_elementwise",
+                                  "down_absmax_f32", "down_absmax_bs128"])
+def test_dequant_bit_exact_vs_reference_golden(name, ref, m355, cuda):
+    gold = json.load(open(os.path.join(GOLD, "dequant_golden.json")))["cases"][name]
+    case = ref.golden_dequant_case(name)
+    a = ref.resolve_absmax(case["absmax"], case["nested_map"], case["nested_absmax"])
+    n = case["n_params"]
+    out = m355.nf4_dequant(_to_dev(case["q"], cuda), _to_dev(a, cuda), blocksize=n // a.size)
+    torch.cuda.synchronize()
+    bits = out.cpu().numpy().view(np.uint16)
+    assert hashlib.sha256(bits.tobytes()).hexdigest() == gold["sha256"]
+    want = ref.nf4_dequant(case["q"], n, a).view(np.uint16)
+    assert np.array_equal(bits, want)
+
+
+def test_dequant_rejects_bad_arguments(m355, cuda):
+    q = torch.zeros(64, dtype=torch.uint8, device=cuda)
+    a = torch.ones(2, dtype=torch.float32, device=cuda)
+    with pytest.raises(m355.Mi355LibraryError):
+        m355.nf4_dequant(q.cpu(), a)
+    with pytest.raises(ValueError):
+        m355.nf4_dequant(q, a, blocksize=32)
+    out = torch.empty(128, dtype=torch.float16, device=cuda)
+    rc = m355.load().m355_nf4_dequant(q.data_ptr(), a.data_ptr(), 128, 12, out.data_ptr(), None)
+    assert rc < 0 and b"blocksize" in m355.load().m355_last_error()
+
+
+def test_repack_layout(ref, m355, cuda):
+    rows, cols = 96, 192
+    q = ref.fill_bytes(5, rows * cols // 2)
+    a = np.arange(rows * cols // 64, dtype=np.float32)
+    qt, at = m355.repack_nf4(_to_dev(q, cuda), _to_dev(a, cuda), rows, cols)
+    qt, at = qt.cpu().numpy(), at.cpu().numpy()
+    NB, P = cols // 64, rows // 32
+    qrows = q.reshape(rows, cols // 2)
+    for p in range(P):
+        for b in range(NB):
+            for lane in range(64):
+                r, g = lane & 15, lane >> 4
+                base = ((p * NB + b) * 64 + lane) * 16
+                c0 = (64 * b + 16 * g) // 2
+                assert np.array_equal(qt[base:base + 8], qrows[16 * p + r, c0:c0 + 8])
+                assert np.array_equal(qt[base + 8:base + 16], qrows[16 * (p + P) + r, c0:c0 + 8])
+    am = a.reshape(rows, NB)
+    for p in range(P):
+        for half in range(2):
+            for g in range(4):
+                for b in range(NB):
+                    for i in range(4):
+                        o = (((p * 2 + half) * 4 + g) * NB + b) * 4 + i
+                        assert at[o] == am[16 * (p + half * P) + 4 * g + i, b]
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,E,k,bias", [(1, 32, 4, False), (32, 32, 4, True), (7, 128, 4, False), (3, 8, 2, True)])
+def test_router_vs_oracle(T, E, k, bias, ref, m355, cuda):
+    H = 2880
+    x = ref.normal_f16(ref.stream_seed(T, E, 1), (T, H))
+    wr = ref.normal_f16(ref.stream_seed(T, E, 2), (E, H), 0.02)
+    br = ref.normal_f16(ref.stream_seed(T, E, 3), (E,), 0.1) if bias else None
+    ids_r, w_r, lg_r = ref.router_topk(x, wr, br, k)
+    ids, w, lg = m355.router_topk(_to_dev(x, cuda), _to_dev(wr, cuda), None if br is None else _to_dev(br, cuda), k,
+                                  want_logits=True)
+    ids, w, lg = ids.cpu().numpy(), w.cpu().numpy(), lg.cpu().numpy()
+    # logits are fp16 roundings of sums taken in different orders: allow one fp16 ulp
+    assert np.abs(lg.astype(np.float32) - lg_r.astype(np.float32)).max() <= 2e-3 * max(1.0, np.abs(lg_r.astype(np.float32)).max())
+    # selection must agree wherever the oracle's k-th and (k+1)-th logits are separated
+    srt = np.sort(lg_r.astype(np.float32), axis=1)[:, ::-1]
+    clear = (srt[:, k - 1] - srt[:, k]) > 4e-3 if E > k else np.ones(T, bool)
+    gaps = np.diff(-np.sort(-lg_r.astype(np.float32), axis=1)[:, :k], axis=1) if k > 1 else np.ones((T, 1))
+    clear &= (np.abs(gaps) > 4e-3).all(axis=1)
+    assert clear.any()
+    assert np.array_equal(ids[clear], ids_r[clear])
+    assert np.abs(w[clear] - w_r[clear]).max() < 5e-3
+    np.testing.assert_allclose(w.sum(axis=1), 1.0, rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["fwd_full_T3", "fwd_small_T37"])
+def test_topk_softmax_vs_reference_golden(name, ref, m355, cuda):
+    c = ref.golden_forward_case(name)
+    ids_g = np.load(os.path.join(GOLD, name + ".topk_ids.npy"))
+    w_g = np.load(os.path.join(GOLD, name + ".topk_w.npy")).astype(np.float32)
+    ids, w = m355.topk_softmax(_to_dev(c["logits"], cuda), c["k"])
+    ids, w = ids.cpu().numpy(), w.cpu().numpy()
+    lg = c["logits"].astype(np.float32)
+    untied = np.array([len(np.unique(np.sort(r)[::-1][:c["k"] + 1])) == min(c["k"] + 1, c["E"]) for r in lg])
+    assert np.array_equal(ids[untied], ids_g[untied])
+    assert np.abs(w[untied] - w_g[untied]).max() <= 1e-3   # golden weights are fp16
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(("fwd_full_T1", "fwd_full_T3", "fwd_small_T37")))
+def test_moe_forward_vs_reference_golden(name, ref, m355, cuda):
+    c = ref.golden_forward_case(name)
+    H, FF, E, k = c["H"], c["FF"], c["E"], c["k"]
+    ids_g = np.load(os.path.join(GOLD, name + ".topk_ids.npy"))
+    w_g = np.load(os.path.join(GOLD, name + ".topk_w.npy")).astype(np.float32)
+    out_g = np.load(os.path.join(GOLD, name + ".out.npy"))
+    tl = tiled_layer(m355, c, E, H, FF, cuda)
+    out = m355.moe_nf4_forward(_to_dev(c["x"], cuda), _to_dev(ids_g, cuda), _to_dev(w_g, cuda), *tl,
+                               E_local=E, e_first=0, H=H, FF=FF)
+    torch.cuda.synchronize()
+    _close(out.cpu().numpy(), out_g)
+
+
+@pytest.mark.parametrize("T,E,k", [(1, 32, 4), (32, 32, 4), (40, 4, 2)])
+def test_moe_forward_full_size_vs_oracle(T, E, k, ref, m355, cuda):
+    """gpt-oss-20b expert shapes; T=40 with 4 experts puts ~20 tokens on an expert (two token tiles)."""
+    H = FF = 2880
+    sd = ref.stream_seed(T, E, k, 77)
+    layer = ref.synth_layer(sd, E, H, FF)
+    x = ref.normal_f16(ref.stream_seed(sd, 1), (T, H))
+    wr = ref.normal_f16(ref.stream_seed(sd, 2), (E, H), 0.02)
+    ids, w, _ = ref.router_topk(x, wr, None, k)
+    want = ref.moe_forward(x, ids, w, **layer, E_local=E, H=H, FF=FF)
+    tl = tiled_layer(m355, layer, E, H, FF, cuda)
+    out = m355.moe_nf4_forward(_to_dev(x, cuda), _to_dev(ids, cuda), _to_dev(w, cuda), *tl, E_local=E, e_first=0,
+                               H=H, FF=FF)
+    torch.cuda.synchronize()
+    _close(out.cpu().numpy(), want)
+    # the layer is linear in the routing weights: doubling w doubles the output (fp32 combine)
+    o1 = m355.moe_nf4_forward(_to_dev(x, cuda), _to_dev(ids, cuda), _to_dev(w, cuda), *tl, E_local=E, e_first=0,
+                              H=H, FF=FF, flags=0)
+    o2 = m355.moe_nf4_forward(_to_dev(x, cuda), _to_dev(ids, cuda), _to_dev(2 * w, cuda), *tl, E_local=E, e_first=0,
+                              H=H, FF=FF, flags=0)
+    _close(o2.float().cpu().numpy(), 2 * o1.float().cpu().numpy(), rtol=1e-3)
+
+
+def test_moe_expert_shards_sum_to_whole(ref, m355, cuda):
+    """Expert-parallel contract: the outputs of disjoint expert shards add up to the unsharded layer."""
+    H, FF, E, k, T = 256, 192, 8, 3, 19
+    sd = ref.stream_seed(4242)
+    layer = ref.synth_layer(sd, E, H, FF)
+    x = ref.normal_f16(ref.stream_seed(sd, 1), (T, H))
+    lg = ref.normal_f16(ref.stream_seed(sd, 2), (T, E), 1.5)
+    ids, w = m355.topk_softmax(_to_dev(lg, cuda), k)
+    w13_q, w13_a, w2_q, w2_a = tiled_layer(m355, layer, E, H, FF, cuda)
+    xd = _to_dev(x, cuda)
+    whole = m355.moe_nf4_forward(xd, ids, w, w13_q, w13_a, w2_q, w2_a, E_local=E, e_first=0, H=H, FF=FF, flags=0)
+    acc = torch.zeros((T, H), dtype=torch.float32, device=cuda)
+    for r in range(4):
+        sl = slice(2 * r, 2 * r + 2)
+        part = m355.moe_nf4_forward(xd, ids, w, w13_q[sl].contiguous(), w13_a[sl].contiguous(), w2_q[sl].contiguous(),
+                                    w2_a[sl].contiguous(), E_local=2, e_first=2 * r, H=H, FF=FF, flags=0)
+        acc += part.float()
+    _close(acc.cpu().numpy(), whole.float().cpu().numpy(), rtol=2e-3)
+    want = ref.moe_forward(x, ids.cpu().numpy(), w.cpu().numpy(), **layer, E_local=E, H=H, FF=FF, flags=0)
+    _close(whole.cpu().numpy(), want)
+
+
+def test_moe_empty_batch_and_errors(m355, cuda):
+    z = torch.zeros(256, dtype=torch.uint8, device=cuda)
+    f = torch.zeros(64, dtype=torch.float32, device=cuda)
+    x = torch.zeros((0, 64), dtype=torch.float16, device=cuda)
+    ids = torch.zeros((0, 1), dtype=torch.int32, device=cuda)
+    w = torch.zeros((0, 1), dtype=torch.float32, device=cuda)
+    out = m355.moe_nf4_forward(x, ids, w, z, f, z, f, E_local=1, e_first=0, H=64, FF=64)
+    assert out.shape == (0, 64)
+    with pytest.raises(m355.Mi355LibraryError, match="unsupported shape"):
+        m355.moe_nf4_forward(torch.zeros((1, 60), dtype=torch.float16, device=cuda),
+                             torch.zeros((1, 1), dtype=torch.int32, device=cuda),
+                             torch.ones((1, 1), dtype=torch.float32, device=cuda), z, f, z, f,
+                             E_local=1, e_first=0, H=60, FF=64)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ctx", [[1], [256, 17, 100], [700, 3, 257, 512], [0, 5]])
+def test_paged_attention_vs_oracle(ctx, ref, m355, cuda):
+    """No reference output exists for attention (it lives in FlashAttention-2): parity unpinned, checked
+    against the oracle's fp32 softmax attention.  Tolerance 2e-3 * max|out| + 1e-5."""
+    B, Hq, Hkv, D, bs = len(ctx), 64, 8, 64, 16
+    max_ctx = max(max(ctx), 1)
+    max_blocks = (max_ctx + bs - 1) // bs
+    nblk = B * max_blocks + 3
+    sd = ref.stream_seed(*ctx, 9)
+    q = ref.normal_f16(ref.stream_seed(sd, 1), (B, Hq, D))
+    kc = ref.normal_f16(ref.stream_seed(sd, 2), (nblk, bs, Hkv, D))
+    vc = ref.normal_f16(ref.stream_seed(sd, 3), (nblk, bs, Hkv, D))
+    perm = np.argsort(ref.uniform01(ref.stream_seed(sd, 4), nblk)).astype(np.int32)   # scattered physical blocks
+    bt = perm[:B * max_blocks].reshape(B, max_blocks).copy()
+    cl = np.array(ctx, dtype=np.int32)
+    scale = D ** -0.5
+    want = ref.paged_attn_decode(q, kc, vc, bt, cl, scale)
+    out = m355.paged_attn_decode(_to_dev(q, cuda), _to_dev(kc, cuda), _to_dev(vc, cuda), _to_dev(bt, cuda),
+                                 _to_dev(cl, cuda), max_ctx=max_ctx, scale=scale)
+    torch.cuda.synchronize()
+    _close(out.cpu().numpy(), want)
