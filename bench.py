@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""Decode-step benchmark of the NF4 MoE hot path on MI355X.
+
+One "step" = one decode token for every sequence of the batch through the hot path of all 24 layers of a
+gpt-oss-20b-shaped model: paged-attention decode, router top-k, fused NF4 MoE (gate/up GEMM, down GEMM,
+combine).  Nothing outside that path runs in the timed region (no qkv/o projections, norms, lm_head).
+Weights are synthetic (random NF4 codes and absmax, already in tile order), inputs are resident in HBM.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+      bench.py --gpus N --steps K --warmup W
+
+With N > 1 the 32 experts of every layer are sharded over the ranks (expert parallelism, two all-to-alls per
+layer); each rank keeps its own batch (attention and router are data-parallel), so the global batch is
+N * batch-per-gpu ("weak" scaling).  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H = FF = 2880
+E, TOPK, LAYERS = 32, 4, 24
+HQ, HKV, D, BLOCK = 64, 8, 64, 16
+GATE_UP_BYTES = (2 * FF * H) // 2 + (2 * FF * H) // 64      # packed codes + 1 B absmax per 64: 8,553,600
+DOWN_BYTES = (H * FF) // 2 + (H * FF) // 64                  # 4,276,800
+HBM_PEAK_GBS = 8000.0
+
+
+class DecodeStep:
+    """State and launch sequence of one decode step for `batch` sequences per rank."""
+
+    def __init__(self, lib, ep_mod, batch, ctx, layers, rank, world, device, group=None, weights_from=None):
+        self.lib, self.batch, self.ctx, self.layers = lib, batch, ctx, layers
+        self.world, self.rank, self.device = world, rank, device
+        g = torch.Generator(device=device)
+        g.manual_seed(355 + rank)
+        e_local = E // world
+        self.e_local, self.e_first = e_local, rank * e_local
+        B = batch
+        nblk_seq = (ctx + BLOCK - 1) // BLOCK
+        nblk = B * nblk_seq
+        self.block_tables = torch.randperm(nblk, device=device, generator=g).to(torch.int32).reshape(B, nblk_seq).contiguous()
+        self.ctx_lens = torch.full((B,), ctx, dtype=torch.int32, device=device)
+        self.L = []
+        for li in range(layers):
+            lay = {}
+            if weights_from is not None:   # share the big tensors with another configuration
+                for key in ("w13_q", "w13_a", "w2_q", "w2_a"):
+                    lay[key] = weights_from.L[li][key]
+            else:
+                lay["w13_q"] = torch.randint(0, 256, (e_local, FF * H), dtype=torch.uint8, device=device, generator=g)
+                lay["w13_a"] = torch.rand((e_local, 2 * FF * H // 64), dtype=torch.float32, device=device, generator=g) * 0.03
+                lay["w2_q"] = torch.randint(0, 256, (e_local, H * FF // 2), dtype=torch.uint8, device=device, generator=g)
+                lay["w2_a"] = torch.rand((e_local, H * FF // 64), dtype=torch.float32, device=device, generator=g) * 0.03
+            lay["wr"] = (torch.randn((E, H), device=device, generator=g) * 0.02).half()
+            lay["x"] = torch.randn((B, H), device=device, generator=g).half()
+            lay["q"] = torch.randn((B, HQ, D), device=device, generator=g).half()
+            lay["kc"] = torch.randn((nblk, BLOCK, HKV, D), device=device, generator=g).half()
+            lay["vc"] = torch.randn((nblk, BLOCK, HKV, D), device=device, generator=g).half()
+            lay["ids"] = torch.empty((B, TOPK), dtype=torch.int32, device=device)
+            lay["w"] = torch.empty((B, TOPK), dtype=torch.float32, device=device)
+            lay["attn_out"] = torch.empty((B, HQ, D), dtype=torch.float16, device=device)
+            lay["out"] = torch.empty((B, H), dtype=torch.float16, device=device)
+            lay["ep"] = ep_mod.ExpertParallelMoE((lay["w13_q"], lay["w13_a"], lay["w2_q"], lay["w2_a"]), num_experts=E,
+                                                 top_k=TOPK, hidden=H, ffn=FF, max_tokens=B, group=group, device=device)
+            self.L.append(lay)
+        self.graph = None
+
+    def run_eager(self):
+        lib = self.lib
+        for lay in self.L:
+            lib.paged_attn_decode(lay["q"], lay["kc"], lay["vc"], self.block_tables, self.ctx_lens, max_ctx=self.ctx,
+                                  scale=D ** -0.5, out=lay["attn_out"])
+            lib.router_topk(lay["x"], lay["wr"], None, TOPK, ids=lay["ids"], w=lay["w"])
+            lay["ep"].forward(lay["x"], lay["ids"], lay["w"], out=lay["out"])
+
+    def capture(self):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self.run_eager()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run_eager()
+        self.graph = g
+
+    def step(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.run_eager()
+
+    def active_experts_per_layer(self):
+        """Distinct local experts hit per layer by the current routing (host sync)."""
+        return [int(torch.unique(lay["ids"]).numel()) for lay in self.L]
+
+
+def timed(stepper, steps, warmup, world):
+    import torch.distributed as dist
+    for _ in range(warmup):
+        stepper.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        stepper.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=stepper.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def roofline_gate_up(stepper, reps=5):
+    """Average duration of moe_gemm_kernel<gate_up> launches (HIP events on the launch stream, layers cycled
+    so the weights come from HBM) against the algorithmic bytes of the experts each launch streams."""
+    lib = stepper.lib
+    F = lib.FLAG_FP16_COMBINE
+    only_gate_up = F | lib.FLAG_SKIP_ROUTE | lib.FLAG_SKIP_DOWN | lib.FLAG_SKIP_COMBINE
+    only_down = F | lib.FLAG_SKIP_ROUTE | lib.FLAG_SKIP_GATE_UP | lib.FLAG_SKIP_COMBINE
+    if stepper.world != 1:
+        return None
+    stepper.run_eager()
+    torch.cuda.synchronize()
+    active = stepper.active_experts_per_layer()
+    res = {}
+    for lay in stepper.L:   # every layer owns a workspace: leave its routing (and h for the down GEMM) in place
+        ep = lay["ep"]
+        lay["_args"] = dict(E_local=ep.epr, e_first=0, H=H, FF=FF, workspace=ep.workspace, out=lay["out"])
+        lib.moe_nf4_forward(lay["x"], lay["ids"], lay["w"], *ep.weights, flags=F | lib.FLAG_SKIP_COMBINE, **lay["_args"])
+    torch.cuda.synchronize()
+    for name, flg, per_expert in (("gate_up", only_gate_up, GATE_UP_BYTES), ("down", only_down, DOWN_BYTES)):
+        def launches():
+            for lay in stepper.L:
+                lib.moe_nf4_forward(lay["x"], lay["ids"], lay["w"], *lay["ep"].weights, flags=flg, **lay["_args"])
+        # one graph of the 24 back-to-back launches of this kernel, so host launch cost stays out of the events
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            launches()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            launches()
+        g.replay()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            g.replay()
+        b.record()
+        b.synchronize()
+        avg_us = a.elapsed_time(b) * 1e3 / (reps * len(stepper.L))
+        bytes_per_launch = sum(active) / len(active) * per_expert
+        res[name] = dict(avg_us=avg_us, bytes=bytes_per_launch, gbs=bytes_per_launch / (avg_us * 1e-6) / 1e9)
+        del g
+    return res, active
+
+
+def cpu_baseline():
+    """The reference's CPU path for one MoE layer and one token (dequant of the 4 routed experts + fp16 matmuls),
+    timed with the oracle port on this host's cores; scaled to 24 layers."""
+    from oracle import ref
+    ref.build()
+    import numpy as np
+    layer = ref.synth_layer(ref.stream_seed(9001), 4, H, FF)
+    x = ref.normal_f16(ref.stream_seed(9002), (1, H))
+    ids = np.arange(4, dtype=np.int32).reshape(1, 4)
+    w = np.full((1, 4), 0.25, dtype=np.float32)
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        ref.moe_forward(x, ids, w, **layer, E_local=4, H=H, FF=FF)
+        ts.append(time.perf_counter() - t0)
+    t_stream = sorted(ts)[len(ts) // 2]
+    w13 = np.stack([ref.nf4_dequant(layer["w13_q"][e], 2 * FF * H, layer["w13_absmax"][e]) for e in range(4)])
+    w2 = np.stack([ref.nf4_dequant(layer["w2_q"][e], H * FF, layer["w2_absmax"][e]) for e in range(4)])
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        ref.moe_forward(x, ids, w, w13_f16=w13, w2_f16=w2, E_local=4, H=H, FF=FF)
+        ts.append(time.perf_counter() - t0)
+    t_res = sorted(ts)[len(ts) // 2]
+    return {
+        "value": 1.0 / (LAYERS * t_stream), "unit": "tokens/s", "cores": ref.threads(), "kind": "port",
+        "sample": "1 MoE layer, 1 token, 4 routed experts: NF4->fp16 dequant of gate_up+down then fp16 matmuls "
+                  "(streaming, as the reference does), median of 5, scaled x24 layers; attention not included",
+        "ms_per_layer_streaming": t_stream * 1e3, "ms_per_layer_resident_fp16": t_res * 1e3,
+        "resident_fp16_tokens_per_s": 1.0 / (LAYERS * t_res),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-per-gpu", type=int, default=32)
+    ap.add_argument("--ctx", type=int, default=256)
+    ap.add_argument("--layers", type=int, default=LAYERS)
+    ap.add_argument("--eager", action="store_true", help="do not capture the step in a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bs1", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    import gpt_oss_vllm_amd  # noqa: F401
+    from gpt_oss_vllm_amd import ep as ep_mod
+    from gpt_oss_vllm_amd import lib
+    lib.load()
+
+    main_step = DecodeStep(lib, ep_mod, a.batch_per_gpu, a.ctx, a.layers, rank, world, device)
+    main_step.run_eager()          # first call sets kernel attributes; must precede graph capture
+    torch.cuda.synchronize()
+    use_graph = (world == 1) and not a.eager
+    if use_graph:
+        main_step.capture()
+    dt = timed(main_step, a.steps, a.warmup, world)
+    tokens = a.batch_per_gpu * world
+    result = {
+        "metric": "decode tokens/sec gpt-oss-20b NF4 (hot path: paged-attn + router + fused NF4 MoE, 24 layers)",
+        "value": tokens * a.steps / dt, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16", "data": "synthetic",
+        "config": {
+            "workload": (f"gpt-oss-20b-shaped NF4 decode, bs={a.batch_per_gpu} per GPU (global {tokens}), ctx {a.ctx}, "
+                         f"{a.layers} layers, H=FF=2880, E=32 top-4, 64q/8kv heads d=64; "
+                         + ("1 GPU: BASELINE configs[2]" if world == 1 else f"experts sharded over {world} GPUs (EP, all-to-all): BASELINE configs[3] shape")),
+            "batch_per_gpu": a.batch_per_gpu, "global_batch": tokens, "seq_len": a.ctx,
+            "parallelism": "single" if world == 1 else f"ep{world}+dp{world}", "hip_graph": use_graph,
+        },
+    }
+
+    if not a.no_bs1:
+        # BASELINE configs[1]: bs=1 greedy decode, seq_len 256 (per GPU when N > 1)
+        del main_step.graph
+        main_step.graph = None
+        bs1 = DecodeStep(lib, ep_mod, 1, a.ctx, a.layers, rank, world, device, weights_from=main_step)
+        bs1.run_eager()
+        torch.cuda.synchronize()
+        if use_graph:
+            bs1.capture()
+        dt1 = timed(bs1, a.steps, a.warmup, world)
+        result["bs1"] = {"value": world * a.steps / dt1, "unit": "tokens/s", "ms_per_step": dt1 / a.steps * 1e3,
+                         "workload": f"bs=1 per GPU (global {world}), ctx {a.ctx}: BASELINE configs[1]" if world == 1
+                         else f"bs=1 per GPU (global {world}), ctx {a.ctx}, EP{world}"}
+        if rank == 0 and world == 1 and not a.no_roofline:
+            bs1.graph = None
+            r1, act1 = roofline_gate_up(bs1)
+            result["bs1"]["roofline_gate_up"] = {"achieved": r1["gate_up"]["gbs"], "frac": r1["gate_up"]["gbs"] / HBM_PEAK_GBS,
+                                                 "avg_us": r1["gate_up"]["avg_us"], "down_gbs": r1["down"]["gbs"],
+                                                 "down_avg_us": r1["down"]["avg_us"]}
+        del bs1
+
+    if rank == 0 and world == 1 and not a.no_roofline:
+        r, active = roofline_gate_up(main_step)
+        result["roofline"] = {
+            "bound": "hbm", "kernel": "moe_gemm_kernel<0> (gate_up)", "achieved": r["gate_up"]["gbs"], "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": r["gate_up"]["gbs"] / HBM_PEAK_GBS, "traffic": None,
+            "avg_us": r["gate_up"]["avg_us"], "algorithmic_bytes_per_launch": r["gate_up"]["bytes"],
+            "mean_active_experts": sum(active) / len(active),
+            "down_kernel": {"achieved": r["down"]["gbs"], "avg_us": r["down"]["avg_us"],
+                            "frac": r["down"]["gbs"] / HBM_PEAK_GBS},
+        }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline()
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -341,7 +341,10 @@ extern "C" int m355_moe_nf4_forward(const void* x_f16, int T, const int32_t* ids
     const int mt_rows = T < MOE_MAX_MT ? T : MOE_MAX_MT;
     const int slots = P < E_local ? P : E_local;
 
-    static bool attr_set = false;
+    static bool attr_done[64] = {false};   // per device: the attribute belongs to the device's code object
+    int dev = 0;
+    if (int rc = hip_status(hipGetDevice(&dev), "hipGetDevice")) return rc;
+    bool& attr_set = attr_done[dev & 63];
     if (!attr_set) {
         int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_gemm_kernel<0>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
@@ -355,23 +358,27 @@ extern "C" int m355_moe_nf4_forward(const void* x_f16, int T, const int32_t* ids
     if (lds13 > 160 * 1024 || lds2 > 160 * 1024)
         return fail(-2, "m355_moe_nf4_forward: H or FF too large for the LDS activation tile (%d / %d bytes)", lds13, lds2);
 
-    moe_route_kernel<<<dim3(1), dim3(ROUTE_THREADS), 0, st>>>(ids, P, E_local, e_first, ws.n_active, ws.offsets, ws.active,
-                                                              ws.sorted, ws.inv);
-    M355_LAUNCH_CHECK("moe_route_kernel");
-    {
+    if (!(flags & M355_FLAG_SKIP_ROUTE)) {
+        moe_route_kernel<<<dim3(1), dim3(ROUTE_THREADS), 0, st>>>(ids, P, E_local, e_first, ws.n_active, ws.offsets,
+                                                                  ws.active, ws.sorted, ws.inv);
+        M355_LAUNCH_CHECK("moe_route_kernel");
+    }
+    if (!(flags & M355_FLAG_SKIP_GATE_UP)) {
         const int R = 2 * FF, NP = R / 32;
         moe_gemm_kernel<0><<<dim3((NP + MOE_PAIRS - 1) / MOE_PAIRS, slots), dim3(MOE_THREADS), lds13, st>>>(
             (const half_t*)x_f16, w13_q, w13_absmax, ws.n_active, ws.offsets, ws.active, ws.sorted, H, R, k, mt_rows, ws.h);
         M355_LAUNCH_CHECK("moe_gemm_kernel<gate_up>");
     }
-    {
+    if (!(flags & M355_FLAG_SKIP_DOWN)) {
         const int R = H, NP = R / 32;
         moe_gemm_kernel<1><<<dim3((NP + MOE_PAIRS - 1) / MOE_PAIRS, slots), dim3(MOE_THREADS), lds2, st>>>(
             ws.h, w2_q, w2_absmax, ws.n_active, ws.offsets, ws.active, ws.sorted, FF, R, k, mt_rows, ws.y);
         M355_LAUNCH_CHECK("moe_gemm_kernel<down>");
     }
-    moe_combine_kernel<<<dim3(T), dim3(256), 0, st>>>(ws.y, ws.inv, w, H, k, (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0,
-                                                      (half_t*)out_f16);
-    M355_LAUNCH_CHECK("moe_combine_kernel");
+    if (!(flags & M355_FLAG_SKIP_COMBINE)) {
+        moe_combine_kernel<<<dim3(T), dim3(256), 0, st>>>(ws.y, ws.inv, w, H, k, (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0,
+                                                          (half_t*)out_f16);
+        M355_LAUNCH_CHECK("moe_combine_kernel");
+    }
     return 0;
 }

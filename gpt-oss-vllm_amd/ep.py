@@ -1,0 +1,104 @@
+"""Expert parallelism for one MoE layer: experts sharded over the ranks of a node, tokens exchanged by
+two all-to-alls (dispatch, combine) through torch.distributed (backend "nccl" = RCCL over xGMI).
+
+The reference is single-GPU (tensor_parallel_size=1, patches/test_gptoss_bnb.py:30); this module is the
+multi-GPU layer the path gains here.  Expert e lives on rank e // (E / world_size).
+
+Per layer and rank, with T local tokens and N ranks:
+  pack      send[r, t] = (x[t], ids[t], w[t]) if token t routes an expert to rank r, else ids = -1
+  dispatch  all_to_all_single of fixed-size chunks (capacity = T rows per peer, so no size exchange)
+  unpack    -> x_all [N*T, H], ids_all, w_all
+  experts   partial[n*T + t] = sum over this rank's experts of w * expert(x)   (one fused MoE forward)
+  combine   all_to_all_single of the partial rows back to the owners
+  reduce    out[t] = sum over ranks of their partial rows (fp32 sum, rank order)
+
+`ops` supplies the device work.  The product uses HipOps (the C ABI); tests may pass a CPU stand-in to
+exercise the exchange logic over gloo.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class HipOps:
+    """Device work through libmoe355.so.  Raises if the library or the GPU is missing."""
+
+    def __init__(self):
+        from . import lib
+        lib.load()
+        self.lib = lib
+
+    def row_bytes(self, H, k):
+        return self.lib.ep_row_bytes(H, k)
+
+    def pack(self, x, ids, w, n_ranks, epr, send):
+        self.lib.ep_pack(x, ids, w, n_ranks, epr, send)
+
+    def unpack(self, recv, NT, k, H, x_all, ids_all, w_all):
+        self.lib.ep_unpack(recv, NT, k, H, x_all, ids_all, w_all)
+
+    def reduce(self, recv, n_ranks, T, H, out):
+        self.lib.ep_reduce(recv, n_ranks, T, H, out)
+
+    def moe(self, x, ids, w, weights, E_local, e_first, H, FF, workspace, out, flags):
+        self.lib.moe_nf4_forward(x, ids, w, *weights, E_local=E_local, e_first=e_first, H=H, FF=FF,
+                                 workspace=workspace, out=out, flags=flags)
+
+    def workspace_bytes(self, T, k, H, FF, E_local):
+        return self.lib.moe_workspace_bytes(T, k, H, FF, E_local)
+
+
+class ExpertParallelMoE:
+    """One MoE layer's expert shard plus the buffers of its token exchange (allocated once, reused)."""
+
+    def __init__(self, weights, *, num_experts: int, top_k: int, hidden: int, ffn: int, max_tokens: int,
+                 group: Optional[dist.ProcessGroup] = None, ops=None, device=None, flags: int = 1):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if num_experts % self.world:
+            raise ValueError(f"{num_experts} experts do not split over {self.world} ranks")
+        self.E, self.k, self.H, self.FF = num_experts, top_k, hidden, ffn
+        self.epr = num_experts // self.world
+        self.e_first = self.rank * self.epr
+        self.weights = weights          # (w13_q, w13_absmax, w2_q, w2_absmax) of the local experts, tile order
+        self.ops = ops if ops is not None else HipOps()
+        self.flags = flags
+        self.T = max_tokens
+        dev = device if device is not None else weights[0].device
+        N, T, H, k = self.world, max_tokens, hidden, top_k
+        rb = self.ops.row_bytes(H, k)
+        self.row_bytes = rb
+        self.send = torch.empty(N * T * rb, dtype=torch.uint8, device=dev)
+        self.recv = torch.empty(N * T * rb, dtype=torch.uint8, device=dev)
+        self.x_all = torch.zeros((N * T, H), dtype=torch.float16, device=dev)
+        self.ids_all = torch.empty((N * T, k), dtype=torch.int32, device=dev)
+        self.w_all = torch.empty((N * T, k), dtype=torch.float32, device=dev)
+        self.partial = torch.empty((N * T, H), dtype=torch.float16, device=dev)
+        self.back = torch.empty((N * T, H), dtype=torch.float16, device=dev)
+        self.workspace = torch.empty(max(256, self.ops.workspace_bytes(N * T, k, H, ffn, self.epr)),
+                                     dtype=torch.uint8, device=dev)
+
+    def forward(self, x: torch.Tensor, ids: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None):
+        """x [T, H] fp16, ids [T, k] int32 (global expert ids), w [T, k] fp32 -> out [T, H] fp16.
+        T must equal the capacity the layer was built with (decode batches are fixed-size)."""
+        T = x.shape[0]
+        if T != self.T:
+            raise ValueError(f"this layer exchanges exactly {self.T} tokens per rank, got {T}")
+        N, H, k = self.world, self.H, self.k
+        if out is None:
+            out = torch.empty((T, H), dtype=torch.float16, device=x.device)
+        if N == 1:
+            self.ops.moe(x, ids, w, self.weights, self.epr, 0, H, self.FF, self.workspace, out, self.flags)
+            return out
+        self.ops.pack(x, ids, w, N, self.epr, self.send)
+        dist.all_to_all_single(self.recv, self.send, group=self.group)
+        self.ops.unpack(self.recv, N * T, k, H, self.x_all, self.ids_all, self.w_all)
+        self.ops.moe(self.x_all, self.ids_all, self.w_all, self.weights, self.epr, self.e_first, H, self.FF,
+                     self.workspace, self.partial, self.flags)
+        dist.all_to_all_single(self.back.view(-1), self.partial.view(-1), group=self.group)
+        self.ops.reduce(self.back, N, T, H, out)
+        return out

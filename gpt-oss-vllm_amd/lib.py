@@ -16,12 +16,13 @@ LIB_PATH = os.path.join(_HERE, "libmoe355.so")
 
 ACT_SILU_CONCAT = 0
 FLAG_FP16_COMBINE = 1
+FLAG_SKIP_ROUTE, FLAG_SKIP_GATE_UP, FLAG_SKIP_DOWN, FLAG_SKIP_COMBINE = 0x100, 0x200, 0x400, 0x800
 
 # every symbol include/m355.h declares
 EXPORTS = (
     "m355_version", "m355_last_error", "m355_nf4_dequant", "m355_repack_nf4", "m355_router_topk",
     "m355_topk_softmax", "m355_moe_nf4_forward", "m355_moe_workspace_bytes", "m355_paged_attn_decode",
-    "m355_paged_attn_workspace_bytes",
+    "m355_paged_attn_workspace_bytes", "m355_ep_row_bytes", "m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -55,7 +56,12 @@ def load() -> ctypes.CDLL:
     L.m355_paged_attn_decode.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp, vp]
     L.m355_paged_attn_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.m355_paged_attn_workspace_bytes.restype = sz
-    for fn in ("m355_nf4_dequant", "m355_repack_nf4", "m355_router_topk", "m355_topk_softmax",
+    L.m355_ep_row_bytes.argtypes = [i32, i32]
+    L.m355_ep_row_bytes.restype = sz
+    L.m355_ep_pack.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
+    L.m355_ep_unpack.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
+    L.m355_ep_reduce.argtypes = [vp, i32, i32, i32, vp, vp]
+    for fn in ("m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce", "m355_nf4_dequant", "m355_repack_nf4", "m355_router_topk", "m355_topk_softmax",
                "m355_moe_nf4_forward", "m355_paged_attn_decode"):
         getattr(L, fn).restype = i32
     _lib = L
@@ -109,12 +115,16 @@ def repack_nf4(q: torch.Tensor, absmax: torch.Tensor, rows: int, cols: int):
     return qt, at
 
 
-def router_topk(x: torch.Tensor, wr: torch.Tensor, br: Optional[torch.Tensor], k: int, want_logits: bool = False):
+def router_topk(x: torch.Tensor, wr: torch.Tensor, br: Optional[torch.Tensor], k: int, want_logits: bool = False,
+                ids: Optional[torch.Tensor] = None, w: Optional[torch.Tensor] = None):
     """fp16 router linear + top-k + softmax.  Returns (ids int32 [T,k], w fp32 [T,k][, logits fp16 [T,E]])."""
     T, H = x.shape
     E = wr.shape[0]
-    ids = torch.empty((T, k), dtype=torch.int32, device=x.device)
-    w = torch.empty((T, k), dtype=torch.float32, device=x.device)
+    if ids is None:
+        ids = torch.empty((T, k), dtype=torch.int32, device=x.device)
+    if w is None:
+        w = torch.empty((T, k), dtype=torch.float32, device=x.device)
+    _dev(ids, torch.int32, "ids"), _dev(w, torch.float32, "w")
     logits = torch.empty((T, E), dtype=torch.float16, device=x.device) if want_logits else None
     _check(load().m355_router_topk(_dev(x, torch.float16, "x"), _dev(wr, torch.float16, "wr"),
                                    None if br is None else _dev(br, torch.float16, "br"), T, H, E, k,
@@ -176,4 +186,38 @@ def paged_attn_decode(q, kcache, vcache, block_tables, ctx_lens, *, max_ctx: int
         None if workspace is None else _dev(workspace, torch.uint8, "workspace"),
         0 if workspace is None else workspace.numel(), _dev(out, torch.float16, "out"), _stream()),
         "m355_paged_attn_decode")
+    return out
+
+
+def ep_row_bytes(H: int, k: int) -> int:
+    return int(load().m355_ep_row_bytes(H, k))
+
+
+def ep_pack(x, ids, w, n_ranks: int, experts_per_rank: int, send: torch.Tensor):
+    """Fill send [n_ranks, T, row_bytes] (uint8) for the dispatch all-to-all.  m355_ep_pack."""
+    T, k = ids.shape
+    H = x.shape[1]
+    if send.numel() != n_ranks * T * ep_row_bytes(H, k):
+        raise ValueError("ep_pack: send buffer has the wrong size")
+    _check(load().m355_ep_pack(_dev(x, torch.float16, "x"), _dev(ids, torch.int32, "ids"), _dev(w, torch.float32, "w"),
+                               T, k, H, n_ranks, experts_per_rank, _dev(send, torch.uint8, "send"), _stream()),
+           "m355_ep_pack")
+    return send
+
+
+def ep_unpack(recv, NT: int, k: int, H: int, x_all, ids_all, w_all):
+    """Split received rows into activations, expert ids and routing weights.  m355_ep_unpack."""
+    if recv.numel() != NT * ep_row_bytes(H, k):
+        raise ValueError("ep_unpack: recv buffer has the wrong size")
+    _check(load().m355_ep_unpack(_dev(recv, torch.uint8, "recv"), NT, k, H, _dev(x_all, torch.float16, "x_all"),
+                                 _dev(ids_all, torch.int32, "ids_all"), _dev(w_all, torch.float32, "w_all"), _stream()),
+           "m355_ep_unpack")
+
+
+def ep_reduce(recv, n_ranks: int, T: int, H: int, out):
+    """out[t] = sum over ranks of recv[r, t].  m355_ep_reduce."""
+    if recv.numel() != n_ranks * T * H:
+        raise ValueError("ep_reduce: recv buffer has the wrong size")
+    _check(load().m355_ep_reduce(_dev(recv, torch.float16, "recv"), n_ranks, T, H, _dev(out, torch.float16, "out"),
+                                 _stream()), "m355_ep_reduce")
     return out

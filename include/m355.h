@@ -32,6 +32,11 @@ typedef void* m355_stream_t; /* a hipStream_t (NULL = the default stream) */
 #define M355_FLAG_FP16_COMBINE 1 /* routing weights rounded to fp16 and out accumulated over k in fp16, in
                                     k order, as the reference's fp16 tensors do
                                     (patches/unsloth_to_vllm_converter.py:301,306,321) */
+/* Profiling aid: leave out stages of the forward; the workspace must hold what a full call left there. */
+#define M355_FLAG_SKIP_ROUTE 0x100
+#define M355_FLAG_SKIP_GATE_UP 0x200
+#define M355_FLAG_SKIP_DOWN 0x400
+#define M355_FLAG_SKIP_COMBINE 0x800
 
 M355_API int m355_version(void);
 M355_API const char* m355_last_error(void);
@@ -105,6 +110,22 @@ M355_API int m355_paged_attn_decode(const void* q_f16, const void* kcache_f16, c
                                     int D, int block_size, int max_blocks, int max_ctx, float scale,
                                     void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream);
 M355_API size_t m355_paged_attn_workspace_bytes(int B, int Hq, int D, int max_ctx);
+
+/*
+ * Expert-parallel exchange helpers.  No counterpart in the reference (it is single-GPU, tensor_parallel_size=1:
+ * patches/test_gptoss_bnb.py:30); they are the byte movers either side of the two all-to-alls that shard the
+ * experts of one layer over the GPUs of a node (expert e lives on rank e / experts_per_rank).
+ *   m355_ep_pack    builds send [n_ranks][T][row]: row = [x: H fp16][ids: k int32][w: k fp32] padded to 16 B
+ *                   (m355_ep_row_bytes); a token with no expert on a destination gets ids = -1 there, no payload.
+ *   m355_ep_unpack  splits received rows [NT][row] into x_all [NT][H], ids_all [NT][k], w_all [NT][k].
+ *   m355_ep_reduce  out[t] = sum_r recv[r][t] (fp16 partial rows, fp32 sum in rank order), recv [n_ranks][T][H].
+ */
+M355_API size_t m355_ep_row_bytes(int H, int k);
+M355_API int m355_ep_pack(const void* x_f16, const int32_t* ids, const float* w, int T, int k, int H, int n_ranks,
+                          int experts_per_rank, void* send, m355_stream_t stream);
+M355_API int m355_ep_unpack(const void* recv, int NT, int k, int H, void* x_all_f16, int32_t* ids_all, float* w_all,
+                            m355_stream_t stream);
+M355_API int m355_ep_reduce(const void* recv_f16, int n_ranks, int T, int H, void* out_f16, m355_stream_t stream);
 
 #ifdef __cplusplus
 }
