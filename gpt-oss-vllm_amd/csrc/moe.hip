@@ -41,9 +41,13 @@ struct MoeWorkspace {
     int32_t* active;     // [E_local]
     int32_t* sorted;     // [P]   sorted position -> pair index (t*k + kk)
     int32_t* inv;        // [P]   pair index -> sorted position, -1 if the expert is not local
+    int32_t* n_tiles;    // [1]   token tiles (<= mt_rows tokens of one expert) over all active experts
+    int32_t* tile_expert;  // [P + E_local]
+    int32_t* tile_m0;      // [P + E_local]  first token (within the expert) of the tile
     half_t* h;           // [P][FF]
     half_t* y;           // [P][H]
     size_t bytes;
+    int max_pairs;       // P
 };
 
 __host__ inline MoeWorkspace carve_workspace(void* base, int T, int k, int H, int FF, int E_local) {
@@ -56,9 +60,13 @@ __host__ inline MoeWorkspace carve_workspace(void* base, int T, int k, int H, in
     w.active = reinterpret_cast<int32_t*>(b + off);   off = align_up(off + 4 * (size_t)E_local, 256);
     w.sorted = reinterpret_cast<int32_t*>(b + off);   off = align_up(off + 4 * P, 256);
     w.inv = reinterpret_cast<int32_t*>(b + off);      off = align_up(off + 4 * P, 256);
+    w.n_tiles = reinterpret_cast<int32_t*>(b + off);  off = align_up(off + 4, 256);
+    w.tile_expert = reinterpret_cast<int32_t*>(b + off); off = align_up(off + 4 * (P + (size_t)E_local), 256);
+    w.tile_m0 = reinterpret_cast<int32_t*>(b + off);  off = align_up(off + 4 * (P + (size_t)E_local), 256);
     w.h = reinterpret_cast<half_t*>(b + off);         off = align_up(off + 2 * P * FF, 256);
     w.y = reinterpret_cast<half_t*>(b + off);         off = align_up(off + 2 * P * H, 256);
     w.bytes = off;
+    w.max_pairs = (int)P;
     return w;
 }
 
@@ -73,7 +81,10 @@ __global__ __launch_bounds__(ROUTE_THREADS) void moe_route_kernel(const int32_t*
                                                                   int32_t* __restrict__ offsets,
                                                                   int32_t* __restrict__ active,
                                                                   int32_t* __restrict__ sorted,
-                                                                  int32_t* __restrict__ inv) {
+                                                                  int32_t* __restrict__ inv, int mt_rows,
+                                                                  int32_t* __restrict__ n_tiles,
+                                                                  int32_t* __restrict__ tile_expert,
+                                                                  int32_t* __restrict__ tile_m0) {
     __shared__ int cnt[ROUTE_MAX_E];
     __shared__ int cur[ROUTE_MAX_E];
     const int tid = threadIdx.x;
@@ -85,15 +96,20 @@ __global__ __launch_bounds__(ROUTE_THREADS) void moe_route_kernel(const int32_t*
     }
     __syncthreads();
     if (tid == 0) {
-        int run = 0, na = 0;
+        int run = 0, na = 0, nt = 0;
         for (int e = 0; e < E_local; e++) {
             offsets[e] = run;
             cur[e] = run;
             if (cnt[e] > 0) active[na++] = e;
+            for (int m0 = 0; m0 < cnt[e]; m0 += mt_rows) {
+                tile_expert[nt] = e;
+                tile_m0[nt++] = m0;
+            }
             run += cnt[e];
         }
         offsets[E_local] = run;
         *n_active = na;
+        *n_tiles = nt;
     }
     __syncthreads();
     for (int p = tid; p < P; p += ROUTE_THREADS) {
@@ -272,6 +288,181 @@ __global__ __launch_bounds__(MOE_THREADS) void moe_gemm_kernel(const half_t* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Streaming form of the same GEMM for K <= 48 blocks (K <= 3072): a workgroup walks a contiguous range of
+// (expert, row-tile-pair group) items; each wave holds the whole K-part of its item in registers (12 KiB
+// per wave) and fetches the next item's bytes before it computes the current one, so a CU always has two
+// items' worth of HBM reads in flight.  The code table is built once per workgroup and the activations are
+// restaged only when the expert changes.  Barriers are raw s_barrier + lgkmcnt(0): a __syncthreads() would
+// also wait for the prefetch.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Write one lane's 4 rows of both tiles for token row `orow`: h = silu(gate) * up (MODE 0) or the raw y (MODE 1).
+template <int MODE>
+__device__ __forceinline__ void gemm_epilogue(const float4_t& accA, const float4_t& accB, half_t* __restrict__ outp,
+                                              int64_t orow, int R, int NP, int p, int g) {
+    if (MODE == 0) {
+        half4_t hv;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float gt = (float)(half_t)accA[r];   // gate and up leave the GEMM as fp16
+            const float up = (float)(half_t)accB[r];
+            const half_t sg = (half_t)(gt / (1.0f + expf(-gt)));
+            hv[r] = (half_t)((float)sg * up);
+        }
+        *reinterpret_cast<half4_t*>(outp + orow * (R / 2) + 16 * p + 4 * g) = hv;
+    } else {
+        half4_t ya, yb;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { ya[r] = (half_t)accA[r]; yb[r] = (half_t)accB[r]; }
+        *reinterpret_cast<half4_t*>(outp + orow * R + 16 * p + 4 * g) = ya;
+        *reinterpret_cast<half4_t*>(outp + orow * R + 16 * (p + NP) + 4 * g) = yb;
+    }
+}
+
+template <int MODE, int PAIRS>
+__global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
+    const half_t* __restrict__ xin, const uint8_t* __restrict__ wq, const float* __restrict__ wam,
+    const int32_t* __restrict__ n_tiles, const int32_t* __restrict__ tile_expert, const int32_t* __restrict__ tile_m0,
+    const int32_t* __restrict__ offsets, const int32_t* __restrict__ sorted, int K, int R, int k_top, int mt_rows,
+    half_t* __restrict__ outp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int THREADS = PAIRS * 256;
+    constexpr int RED1 = PAIRS * (MOE_KPARTS - 1) * 64 * 8 * 4;   // one reduction buffer
+    const int NB = K / 64, NP = R / 32;
+    const int NPG = (NP + PAIRS - 1) / PAIRS;
+    // work item = (token tile of one expert, group of PAIRS row-tile pairs); a workgroup takes a contiguous range
+    const int total = *n_tiles * NPG;
+    const int it0 = (int)((int64_t)blockIdx.x * total / gridDim.x);
+    const int it1 = (int)((int64_t)(blockIdx.x + 1) * total / gridDim.x);
+    if (it0 >= it1) return;
+
+    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
+    unsigned char* red = smem + LUT_BYTES;
+    unsigned char* xs = smem + LUT_BYTES + 2 * RED1;
+    const int XS = K * 2 + XS_PAD;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = wave >> 2, q = wave & 3;
+    const int BQ = (NB + MOE_KPARTS - 1) / MOE_KPARTS;
+    const int bq0 = min(q * BQ, NB), bq1 = min(bq0 + BQ, NB);
+    const int n = lane & 15, g = lane >> 4;
+    const size_t wq_expert = (size_t)R * K / 2, am_expert = (size_t)R * NB;
+
+    // Loads the K-part of item IT into W/SA/SB.  Past the end of the range (VALID false) the same instructions
+    // re-read one resident line instead, so the register buffers are written unconditionally.
+#define M355_LOAD_ITEM(IT, VALID, W, SA, SB)                                                                  \
+    {                                                                                                         \
+        const int itc_ = (VALID) ? (IT) : it0;                                                                \
+        const int tt_ = itc_ / NPG, pg_ = itc_ - tt_ * NPG;                                                   \
+        const int e_ = tile_expert[tt_];                                                                      \
+        const int pc_ = min(pg_ * PAIRS + pl, NP - 1);                                                        \
+        const u32x4_t* wt_ = reinterpret_cast<const u32x4_t*>(wq + (size_t)e_ * wq_expert) + (size_t)pc_ * NB * 64 + lane; \
+        const int step_ = (VALID) ? 64 : 0;                                                                   \
+        _Pragma("unroll") for (int i = 0; i < MOE_CHUNK; i++)                                                 \
+            W[i] = __builtin_nontemporal_load(wt_ + (size_t)min(bq0 + i, NB - 1) * step_);                    \
+        const float4_t* am_ = reinterpret_cast<const float4_t*>(wam + (size_t)e_ * am_expert);                \
+        const int bs_ = min(bq0 + n, NB - 1);                                                                 \
+        SA = am_[((size_t)(pc_ * 2 + 0) * 4 + g) * NB + bs_];                                                 \
+        SB = am_[((size_t)(pc_ * 2 + 1) * 4 + g) * NB + bs_];                                                 \
+    }
+
+    u32x4_t wA[MOE_CHUNK], wB[MOE_CHUNK];
+    float4_t sAa, sBa, sAb, sBb;
+    M355_LOAD_ITEM(it0, true, wA, sAa, sBa)
+
+    {   // code table: THREADS/256 threads share one byte value
+        const float tab[16] = M355_NF4_TABLE;
+        constexpr int TPB = THREADS / 256;          // threads per byte value (1 or 2)
+        const int bv = tid / TPB, sub = tid % TPB;
+        const half2_t hv = {(half_t)tab[bv & 15], (half_t)tab[bv >> 4]};
+        const uint32_t v = __builtin_bit_cast(uint32_t, hv);
+#pragma unroll
+        for (int i = 0; i < 32 / TPB; i++) lut[bv * 32 + sub * (32 / TPB) + i] = v;
+    }
+    const uint32_t* lut_lane = lut + (lane & 31);
+
+    int staged_tile = -1;
+    int round = 0;
+
+#define M355_SBLOCK(I, W, SA, SB)                                                                           \
+    if (bq0 + I < bq1) {                                                                                    \
+        const unsigned char* xb = xrow + (bq0 + I) * 128;                                                   \
+        const half8_t b0 = *reinterpret_cast<const half8_t*>(xb);                                           \
+        const half8_t b1 = *reinterpret_cast<const half8_t*>(xb + 16);                                      \
+        const u32x4_t wv = W[I];                                                                            \
+        const float4_t z = {0.f, 0.f, 0.f, 0.f};                                                            \
+        float4_t pA = __builtin_amdgcn_mfma_f32_16x16x32_f16(lut4(lut_lane, wv[0]), b0, z, 0, 0, 0);        \
+        float4_t pB = __builtin_amdgcn_mfma_f32_16x16x32_f16(lut4(lut_lane, wv[2]), b0, z, 0, 0, 0);        \
+        pA = __builtin_amdgcn_mfma_f32_16x16x32_f16(lut4(lut_lane, wv[1]), b1, pA, 0, 0, 0);                \
+        pB = __builtin_amdgcn_mfma_f32_16x16x32_f16(lut4(lut_lane, wv[3]), b1, pB, 0, 0, 0);                \
+        _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                     \
+            accA[r] += row_bcast<I>(SA[r]) * pA[r];                                                         \
+            accB[r] += row_bcast<I>(SB[r]) * pB[r];                                                         \
+        }                                                                                                   \
+    }
+
+#define M355_DO_ITEM(IT, W, SA, SB, NW, NSA, NSB)                                                             \
+    {                                                                                                         \
+        const int tt = (IT) / NPG, pg = (IT) - tt * NPG;                                                      \
+        const int e = tile_expert[tt];                                                                        \
+        const int m0 = tile_m0[tt];                                                                           \
+        const int pos0 = offsets[e] + m0;                                                                     \
+        const int mt = min(mt_rows, offsets[e + 1] - pos0);                                                   \
+        const int p = pg * PAIRS + pl;                                                                        \
+        const bool live = p < NP;                                                                             \
+        const bool need_stage = tt != staged_tile;                                                            \
+        if (need_stage) {                                                                                     \
+            /* every wave is past the previous reduction barrier, so nobody still reads xs */                 \
+            const int cpr = K / 8;                                                                            \
+            for (int row = 0; row < mt; row++) {                                                              \
+                const int pos = pos0 + row;                                                                   \
+                const int64_t src_row = (MODE == 0) ? (int64_t)(sorted[pos] / k_top) : (int64_t)pos;          \
+                const u32x4_t* src = reinterpret_cast<const u32x4_t*>(xin + src_row * K);                     \
+                for (int c = tid; c < cpr; c += THREADS)                                                      \
+                    *reinterpret_cast<u32x4_t*>(xs + row * XS + c * 16) = src[c];                             \
+            }                                                                                                 \
+            staged_tile = tt;                                                                                 \
+        }                                                                                                     \
+        M355_LOAD_ITEM((IT) + 1, (IT) + 1 < it1, NW, NSA, NSB) /* the next item's bytes fly during this compute */ \
+        if (need_stage) lds_barrier();                                                                        \
+        float4_t accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};                                    \
+        const unsigned char* xrow = xs + min(n, mt - 1) * XS + g * 32;                                        \
+        M355_SBLOCK(0, W, SA, SB) M355_SBLOCK(1, W, SA, SB) M355_SBLOCK(2, W, SA, SB)                         \
+        M355_SBLOCK(3, W, SA, SB) M355_SBLOCK(4, W, SA, SB) M355_SBLOCK(5, W, SA, SB)                         \
+        M355_SBLOCK(6, W, SA, SB) M355_SBLOCK(7, W, SA, SB) M355_SBLOCK(8, W, SA, SB)                         \
+        M355_SBLOCK(9, W, SA, SB) M355_SBLOCK(10, W, SA, SB) M355_SBLOCK(11, W, SA, SB)                       \
+        /* sum the K-parts through LDS (two buffers in turn, so one barrier per item is enough) */            \
+        float4_t* rbuf = reinterpret_cast<float4_t*>(red + (round & 1) * RED1);                               \
+        round++;                                                                                              \
+        if (q > 0) {                                                                                          \
+            float4_t* dst = rbuf + ((size_t)(pl * (MOE_KPARTS - 1) + (q - 1)) * 64 + lane) * 2;               \
+            dst[0] = accA;                                                                                    \
+            dst[1] = accB;                                                                                    \
+        }                                                                                                     \
+        lds_barrier();                                                                                        \
+        if (q == 0 && live) {                                                                                 \
+            _Pragma("unroll") for (int qq = 0; qq < MOE_KPARTS - 1; qq++) {                                   \
+                const float4_t* src = rbuf + ((size_t)(pl * (MOE_KPARTS - 1) + qq) * 64 + lane) * 2;          \
+                accA += src[0];                                                                               \
+                accB += src[1];                                                                               \
+            }                                                                                                 \
+            if (n < mt) gemm_epilogue<MODE>(accA, accB, outp, pos0 + n, R, NP, p, g);                         \
+        }                                                                                                     \
+    }
+
+    for (int it = it0; it < it1; it += 2) {
+        M355_DO_ITEM(it, wA, sAa, sBa, wB, sAb, sBb)
+        if (it + 1 < it1) M355_DO_ITEM(it + 1, wB, sAb, sBb, wA, sAa, sBa)
+    }
+#undef M355_DO_ITEM
+#undef M355_SBLOCK
+#undef M355_LOAD_ITEM
+}
+
 // out[t][c] = sum over the token's local pairs, in k order.  FP16 mode rounds as the reference's fp16
 // tensors do: w -> fp16, product -> fp16, running sum -> fp16.
 __global__ __launch_bounds__(256) void moe_combine_kernel(const half_t* __restrict__ y, const int32_t* __restrict__ inv,
@@ -309,6 +500,68 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const half_t* __restri
 
 static int gemm_lds_bytes(int K, int mt_rows) { return LUT_BYTES + RED_BYTES + mt_rows * (K * 2 + XS_PAD); }
 
+
+template <typename Kern>
+static int allow_big_lds(Kern kern) {
+    return hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                      "hipFuncSetAttribute");
+}
+
+// Once per device: raise the dynamic-LDS limit of the GEMM kernels and read the CU count.
+static int device_setup(int dev, int* cus) {
+    static bool done[64] = {false};
+    static int ncu[64] = {0};
+    const int d = dev & 63;
+    if (!done[d]) {
+        if (int rc = allow_big_lds(&moe_gemm_kernel<0>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_kernel<1>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 1>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 2>)) return rc;
+        int v = 0;
+        if (int rc = hip_status(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute")) return rc;
+        ncu[d] = v > 0 ? v : 256;
+        done[d] = true;
+    }
+    *cus = ncu[d];
+    return 0;
+}
+
+static int stream_lds_bytes(int K, int mt_rows, int pairs) {
+    return LUT_BYTES + 2 * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4 + mt_rows * (K * 2 + XS_PAD);
+}
+
+// W [R][K] per expert.  K <= 48 blocks: streaming kernel, one or two workgroups per CU; else the general kernel.
+template <int MODE>
+static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, const MoeWorkspace& ws, int K, int R,
+                       int k_top, int mt_rows, int slots, half_t* outp, int cus, hipStream_t st) {
+    const int NP = R / 32, NB = K / 64;
+    if (NB <= MOE_KPARTS * MOE_CHUNK) {
+        const int max_tiles = slots + ws.max_pairs / mt_rows;   // sum over experts of ceil(M_e / mt_rows) stays below this
+        const int items2 = max_tiles * ((NP + 1) / 2);
+        if (items2 >= 2 * cus) {
+            const int lds = stream_lds_bytes(K, mt_rows, 2);
+            const int grid = items2 < cus ? items2 : cus;
+            moe_gemm_stream_kernel<MODE, 2><<<dim3(grid), dim3(512), lds, st>>>(xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0,
+                                                                                ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp);
+        } else {
+            const int lds = stream_lds_bytes(K, mt_rows, 1);
+            const int per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
+            const int items1 = max_tiles * NP;
+            const int grid = items1 < per_cu * cus ? items1 : per_cu * cus;
+            moe_gemm_stream_kernel<MODE, 1><<<dim3(grid), dim3(256), lds, st>>>(xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0,
+                                                                                ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp);
+        }
+        M355_LAUNCH_CHECK("moe_gemm_stream_kernel");
+        return 0;
+    }
+    moe_gemm_kernel<MODE><<<dim3((NP + MOE_PAIRS - 1) / MOE_PAIRS, slots), dim3(MOE_THREADS), gemm_lds_bytes(K, mt_rows), st>>>(
+        xin, wq, wam, ws.n_active, ws.offsets, ws.active, ws.sorted, K, R, k_top, mt_rows, outp);
+    M355_LAUNCH_CHECK("moe_gemm_kernel");
+    return 0;
+}
+
 }  // namespace m355
 
 using namespace m355;
@@ -341,39 +594,23 @@ extern "C" int m355_moe_nf4_forward(const void* x_f16, int T, const int32_t* ids
     const int mt_rows = T < MOE_MAX_MT ? T : MOE_MAX_MT;
     const int slots = P < E_local ? P : E_local;
 
-    static bool attr_done[64] = {false};   // per device: the attribute belongs to the device's code object
-    int dev = 0;
+    int dev = 0, cus = 0;
     if (int rc = hip_status(hipGetDevice(&dev), "hipGetDevice")) return rc;
-    bool& attr_set = attr_done[dev & 63];
-    if (!attr_set) {
-        int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_gemm_kernel<0>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
-        if (rc) return rc;
-        rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_gemm_kernel<1>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute");
-        if (rc) return rc;
-        attr_set = true;
-    }
-    const int lds13 = gemm_lds_bytes(H, mt_rows), lds2 = gemm_lds_bytes(FF, mt_rows);
-    if (lds13 > 160 * 1024 || lds2 > 160 * 1024)
-        return fail(-2, "m355_moe_nf4_forward: H or FF too large for the LDS activation tile (%d / %d bytes)", lds13, lds2);
+    if (int rc = device_setup(dev, &cus)) return rc;
+    if (gemm_lds_bytes(H, mt_rows) > 160 * 1024 || gemm_lds_bytes(FF, mt_rows) > 160 * 1024)
+        return fail(-2, "m355_moe_nf4_forward: H or FF too large for the LDS activation tile");
 
     if (!(flags & M355_FLAG_SKIP_ROUTE)) {
         moe_route_kernel<<<dim3(1), dim3(ROUTE_THREADS), 0, st>>>(ids, P, E_local, e_first, ws.n_active, ws.offsets,
-                                                                  ws.active, ws.sorted, ws.inv);
+                                                                  ws.active, ws.sorted, ws.inv, mt_rows, ws.n_tiles,
+                                                                  ws.tile_expert, ws.tile_m0);
         M355_LAUNCH_CHECK("moe_route_kernel");
     }
     if (!(flags & M355_FLAG_SKIP_GATE_UP)) {
-        const int R = 2 * FF, NP = R / 32;
-        moe_gemm_kernel<0><<<dim3((NP + MOE_PAIRS - 1) / MOE_PAIRS, slots), dim3(MOE_THREADS), lds13, st>>>(
-            (const half_t*)x_f16, w13_q, w13_absmax, ws.n_active, ws.offsets, ws.active, ws.sorted, H, R, k, mt_rows, ws.h);
-        M355_LAUNCH_CHECK("moe_gemm_kernel<gate_up>");
+        if (int rc = launch_gemm<0>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st)) return rc;
     }
     if (!(flags & M355_FLAG_SKIP_DOWN)) {
-        const int R = H, NP = R / 32;
-        moe_gemm_kernel<1><<<dim3((NP + MOE_PAIRS - 1) / MOE_PAIRS, slots), dim3(MOE_THREADS), lds2, st>>>(
-            ws.h, w2_q, w2_absmax, ws.n_active, ws.offsets, ws.active, ws.sorted, FF, R, k, mt_rows, ws.y);
-        M355_LAUNCH_CHECK("moe_gemm_kernel<down>");
+        if (int rc = launch_gemm<1>(ws.h, w2_q, w2_absmax, ws, FF, H, k, mt_rows, slots, ws.y, cus, st)) return rc;
     }
     if (!(flags & M355_FLAG_SKIP_COMBINE)) {
         moe_combine_kernel<<<dim3(T), dim3(256), 0, st>>>(ws.y, ws.inv, w, H, k, (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0,
