@@ -20,6 +20,8 @@
 // Dequantisation: a byte holds two codes; a 256-entry table of packed half2 (code[lo], code[hi]) is
 // replicated 32x in LDS (entry address = (byte*32 + lane%32)*4) so a wave's lookups never collide on a bank.
 // The code values are fp16-rounded NF4 entries; scales stay fp32.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace m355 {
@@ -129,7 +131,8 @@ __global__ __launch_bounds__(ROUTE_THREADS) void moe_route_kernel(const int32_t*
 // Broadcast lane (16*row + I)'s value to the 16 lanes of its row.
 template <int I>
 __device__ __forceinline__ float row_bcast(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150 + I, 0xf, 0xf, false));
+    const int iv = __builtin_bit_cast(int, v);   // old = source: every lane is written, no zero-init needed
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x150 + I, 0xf, 0xf, false));
 }
 
 __device__ __forceinline__ half8_t lut4(const uint32_t* lut_lane, uint32_t d) {
@@ -330,6 +333,11 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int THREADS = PAIRS * 256;
     constexpr int RED1 = PAIRS * (MOE_KPARTS - 1) * 64 * 8 * 4;   // one reduction buffer
+    constexpr int NRED = (PAIRS >= 4) ? 1 : 2;                      // 16-wave groups have LDS for one only
+#ifndef M355_FS
+#define M355_FS 1
+#endif
+    constexpr int FS = (PAIRS >= 4) ? 0 : M355_FS;                        // fragment sets - 1 (16 waves rely on occupancy instead)
     const int NB = K / 64, NP = R / 32;
     const int NPG = (NP + PAIRS - 1) / PAIRS;
     // work item = (token tile of one expert, group of PAIRS row-tile pairs); a workgroup takes a contiguous range
@@ -340,39 +348,55 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
 
     uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
     unsigned char* red = smem + LUT_BYTES;
-    unsigned char* xs = smem + LUT_BYTES + 2 * RED1;
+    unsigned char* xs = smem + LUT_BYTES + NRED * RED1;
     const int XS = K * 2 + XS_PAD;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = wave >> 2, q = wave & 3;
-    const int BQ = (NB + MOE_KPARTS - 1) / MOE_KPARTS;
-    const int bq0 = min(q * BQ, NB), bq1 = min(bq0 + BQ, NB);
+    const int bq0 = q * NB / MOE_KPARTS, bq1 = (q + 1) * NB / MOE_KPARTS;   // this wave's blocks: 0..MOE_CHUNK of them
+    const int blast = max(bq1 - 1, bq0);   // block that out-of-part slots re-read (their scale is zero)
     const int n = lane & 15, g = lane >> 4;
     const size_t wq_expert = (size_t)R * K / 2, am_expert = (size_t)R * NB;
 
-    // Loads the K-part of item IT into W/SA/SB.  Past the end of the range (VALID false) the same instructions
-    // re-read one resident line instead, so the register buffers are written unconditionally.
-#define M355_LOAD_ITEM(IT, VALID, W, SA, SB)                                                                  \
+    // Register ring: W[i] holds block i of the current item until its table lookups are issued, then takes the
+    // same block of the NEXT item straight away, so one item's worth of HBM reads (12 KiB per wave) is always in
+    // flight behind the compute.  Past the end of the range the loads re-read one resident line (step 0).
+    u32x4_t W[MOE_CHUNK];
+    float4_t sA, sB, sAn, sBn;
+    const u32x4_t* wt_next;
+    int step_next;
+
+#define M355_POINT_AT(IT, VALID)                                                                              \
     {                                                                                                         \
         const int itc_ = (VALID) ? (IT) : it0;                                                                \
         const int tt_ = itc_ / NPG, pg_ = itc_ - tt_ * NPG;                                                   \
         const int e_ = tile_expert[tt_];                                                                      \
         const int pc_ = min(pg_ * PAIRS + pl, NP - 1);                                                        \
-        const u32x4_t* wt_ = reinterpret_cast<const u32x4_t*>(wq + (size_t)e_ * wq_expert) + (size_t)pc_ * NB * 64 + lane; \
-        const int step_ = (VALID) ? 64 : 0;                                                                   \
-        _Pragma("unroll") for (int i = 0; i < MOE_CHUNK; i++)                                                 \
-            W[i] = __builtin_nontemporal_load(wt_ + (size_t)min(bq0 + i, NB - 1) * step_);                    \
+        wt_next = reinterpret_cast<const u32x4_t*>(wq + (size_t)e_ * wq_expert) + (size_t)pc_ * NB * 64 + lane; \
+        step_next = (VALID) ? 64 : 0;                                                                         \
         const float4_t* am_ = reinterpret_cast<const float4_t*>(wam + (size_t)e_ * am_expert);                \
-        const int bs_ = min(bq0 + n, NB - 1);                                                                 \
-        SA = am_[((size_t)(pc_ * 2 + 0) * 4 + g) * NB + bs_];                                                 \
-        SB = am_[((size_t)(pc_ * 2 + 1) * 4 + g) * NB + bs_];                                                 \
+        const int bs_ = min(bq0 + n, blast);                                                                  \
+        const float keep_ = (bq0 + n < bq1) ? 1.f : 0.f; /* blocks past the K-part count for nothing */       \
+        sAn = am_[((size_t)(pc_ * 2 + 0) * 4 + g) * NB + bs_] * keep_;                                        \
+        sBn = am_[((size_t)(pc_ * 2 + 1) * 4 + g) * NB + bs_] * keep_;                                        \
     }
+#ifdef M355_EXP_NOLOAD   /* experiment: compute on whatever the first loads brought */
+#define M355_LOAD(I) if (it < 0) W[I] = __builtin_nontemporal_load(wt_next + (size_t)min(bq0 + I, blast) * step_next);
+#else
+#define M355_LOAD(I) W[I] = __builtin_nontemporal_load(wt_next + (size_t)min(bq0 + I, blast) * step_next);
+#endif
 
-    u32x4_t wA[MOE_CHUNK], wB[MOE_CHUNK];
-    float4_t sAa, sBa, sAb, sBb;
-    M355_LOAD_ITEM(it0, true, wA, sAa, sBa)
+    M355_POINT_AT(it0, true)
+    {
+        const int it = -1;   // (only read by the no-load experiment build)
+        (void)it;
+#pragma unroll
+        for (int i = 0; i < MOE_CHUNK; i++) M355_LOAD(i)
+    }
+    sA = sAn;
+    sB = sBn;
 
     {   // code table: THREADS/256 threads share one byte value
         const float tab[16] = M355_NF4_TABLE;
@@ -385,82 +409,124 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     }
     const uint32_t* lut_lane = lut + (lane & 31);
 
+    #ifdef M355_WITH_SB   /* pinning the stage order costs ~25 %: the compiler's own interleave is better */
+#define M355_SB __builtin_amdgcn_sched_barrier(0);
+#else
+#define M355_SB
+#endif
+    // Every wave runs MOE_CHUNK blocks per item without branches: blocks past the end of its K-part re-read the
+    // part's last block and carry a zero scale.  Per block: M355_FETCH (16 table lookups = four A fragments, two B
+    // fragments, into fragment set I&1, then the ring load of the next item's block I), M355_MFMA (four MFMAs into
+    // partial set I&1), M355_SCALE (absmax FMAs).  The body runs FETCH(I+1), MFMA(I), SCALE(I-1) in that order so
+    // lookups, matrix cores and VALU overlap.
+#define M355_FETCH(I)                                                                                       \
+    {                                                                                                       \
+        const unsigned char* xb = xrow + min(bq0 + I, blast) * 128;                                       \
+        fb[I & FS][0] = *reinterpret_cast<const half8_t*>(xb);                                               \
+        fb[I & FS][1] = *reinterpret_cast<const half8_t*>(xb + 16);                                          \
+        fa[I & FS][0] = lut4(lut_lane, W[I][0]);                                                             \
+        fa[I & FS][2] = lut4(lut_lane, W[I][2]);                                                             \
+        fa[I & FS][1] = lut4(lut_lane, W[I][1]);                                                             \
+        fa[I & FS][3] = lut4(lut_lane, W[I][3]);                                                             \
+        M355_LOAD(I)                                                                                        \
+    }                                                                                                       \
+    M355_SB
+
+#define M355_MFMA(I)                                                                                        \
+    {                                                                                                       \
+        const float4_t z = {0.f, 0.f, 0.f, 0.f};                                                            \
+        pa[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][0], fb[I & FS][0], z, 0, 0, 0);         \
+        pb[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][2], fb[I & FS][0], z, 0, 0, 0);         \
+        pa[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][1], fb[I & FS][1], pa[I & FS], 0, 0, 0); \
+        pb[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][3], fb[I & FS][1], pb[I & FS], 0, 0, 0); \
+    }                                                                                                       \
+    M355_SB
+
+#define M355_SCALE(I)                                                                                       \
+    _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                         \
+        accA[r] += row_bcast<I>(sA[r]) * pa[I & FS][r];                                                      \
+        accB[r] += row_bcast<I>(sB[r]) * pb[I & FS][r];                                                      \
+    }                                                                                                       \
+    M355_SB
+
+#ifdef M355_EXP_NOCOMPUTE   /* experiment: keep the loads, drop table lookups and MFMAs */
+#undef M355_FETCH
+#undef M355_MFMA
+#undef M355_SCALE
+#define M355_FETCH(I) asm volatile("" ::"v"(W[I])); M355_LOAD(I)
+#define M355_MFMA(I)
+#define M355_SCALE(I) accA[0] += sA[0]; accB[0] += sB[0];
+#endif
+#define M355_STEP(I) M355_FETCH(I + 1) M355_MFMA(I) M355_SCALE(I - 1)
+#define M355_PLAIN(I) M355_FETCH(I) M355_MFMA(I) M355_SCALE(I)
+
     int staged_tile = -1;
     int round = 0;
+    for (int it = it0; it < it1; it++) {
+        const int tt = it / NPG, pg = it - tt * NPG;
+        const int e = tile_expert[tt];
+        const int m0 = tile_m0[tt];
+        const int pos0 = offsets[e] + m0;
+        const int mt = min(mt_rows, offsets[e + 1] - pos0);
+        const int p = pg * PAIRS + pl;
+        const bool live = p < NP;
+        if (tt != staged_tile) {
+            // every wave is past the previous reduction barrier, so nobody still reads xs
+            const int cpr = K / 8;
+            for (int row = 0; row < mt; row++) {
+                const int pos = pos0 + row;
+                const int64_t src_row = (MODE == 0) ? (int64_t)(sorted[pos] / k_top) : (int64_t)pos;
+                const u32x4_t* src = reinterpret_cast<const u32x4_t*>(xin + src_row * K);
+                for (int c = tid; c < cpr; c += THREADS) *reinterpret_cast<u32x4_t*>(xs + row * XS + c * 16) = src[c];
+            }
+            staged_tile = tt;
+            lds_barrier();
+        }
+        M355_POINT_AT(it + 1, it + 1 < it1)
 
-#define M355_SBLOCK(I, W, SA, SB)                                                                           \
-    if (bq0 + I < bq1) {                                                                                    \
-        const unsigned char* xb = xrow + (bq0 + I) * 128;                                                   \
-        const half8_t b0 = *reinterpret_cast<const half8_t*>(xb);                                           \
-        const half8_t b1 = *reinterpret_cast<const half8_t*>(xb + 16);                                      \
-        const u32x4_t wv = W[I];                                                                            \
-        const float4_t z = {0.f, 0.f, 0.f, 0.f};                                                            \
-        float4_t pA = __builtin_amdgcn_mfma_f32_16x16x32_f16(lut4(lut_lane, wv[0]), b0, z, 0, 0, 0);        \
-        float4_t pB = __builtin_amdgcn_mfma_f32_16x16x32_f16(lut4(lut_lane, wv[2]), b0, z, 0, 0, 0);        \
-        pA = __builtin_amdgcn_mfma_f32_16x16x32_f16(lut4(lut_lane, wv[1]), b1, pA, 0, 0, 0);                \
-        pB = __builtin_amdgcn_mfma_f32_16x16x32_f16(lut4(lut_lane, wv[3]), b1, pB, 0, 0, 0);                \
-        _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                     \
-            accA[r] += row_bcast<I>(SA[r]) * pA[r];                                                         \
-            accB[r] += row_bcast<I>(SB[r]) * pB[r];                                                         \
-        }                                                                                                   \
-    }
+        float4_t accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+        const unsigned char* xrow = xs + min(n, mt - 1) * XS + g * 32;
+        half8_t fa[FS + 1][4], fb[FS + 1][2];
+        float4_t pa[FS + 1], pb[FS + 1];
+        if (FS) {
+            M355_FETCH(0) M355_FETCH(1) M355_MFMA(0)
+            M355_STEP(1) M355_STEP(2) M355_STEP(3) M355_STEP(4) M355_STEP(5)
+            M355_STEP(6) M355_STEP(7) M355_STEP(8) M355_STEP(9) M355_STEP(10)
+            M355_MFMA(11) M355_SCALE(10) M355_SCALE(11)
+        } else {
+            M355_PLAIN(0) M355_PLAIN(1) M355_PLAIN(2) M355_PLAIN(3) M355_PLAIN(4) M355_PLAIN(5)
+            M355_PLAIN(6) M355_PLAIN(7) M355_PLAIN(8) M355_PLAIN(9) M355_PLAIN(10) M355_PLAIN(11)
+        }
+        sA = sAn;
+        sB = sBn;
 
-#define M355_DO_ITEM(IT, W, SA, SB, NW, NSA, NSB)                                                             \
-    {                                                                                                         \
-        const int tt = (IT) / NPG, pg = (IT) - tt * NPG;                                                      \
-        const int e = tile_expert[tt];                                                                        \
-        const int m0 = tile_m0[tt];                                                                           \
-        const int pos0 = offsets[e] + m0;                                                                     \
-        const int mt = min(mt_rows, offsets[e + 1] - pos0);                                                   \
-        const int p = pg * PAIRS + pl;                                                                        \
-        const bool live = p < NP;                                                                             \
-        const bool need_stage = tt != staged_tile;                                                            \
-        if (need_stage) {                                                                                     \
-            /* every wave is past the previous reduction barrier, so nobody still reads xs */                 \
-            const int cpr = K / 8;                                                                            \
-            for (int row = 0; row < mt; row++) {                                                              \
-                const int pos = pos0 + row;                                                                   \
-                const int64_t src_row = (MODE == 0) ? (int64_t)(sorted[pos] / k_top) : (int64_t)pos;          \
-                const u32x4_t* src = reinterpret_cast<const u32x4_t*>(xin + src_row * K);                     \
-                for (int c = tid; c < cpr; c += THREADS)                                                      \
-                    *reinterpret_cast<u32x4_t*>(xs + row * XS + c * 16) = src[c];                             \
-            }                                                                                                 \
-            staged_tile = tt;                                                                                 \
-        }                                                                                                     \
-        M355_LOAD_ITEM((IT) + 1, (IT) + 1 < it1, NW, NSA, NSB) /* the next item's bytes fly during this compute */ \
-        if (need_stage) lds_barrier();                                                                        \
-        float4_t accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};                                    \
-        const unsigned char* xrow = xs + min(n, mt - 1) * XS + g * 32;                                        \
-        M355_SBLOCK(0, W, SA, SB) M355_SBLOCK(1, W, SA, SB) M355_SBLOCK(2, W, SA, SB)                         \
-        M355_SBLOCK(3, W, SA, SB) M355_SBLOCK(4, W, SA, SB) M355_SBLOCK(5, W, SA, SB)                         \
-        M355_SBLOCK(6, W, SA, SB) M355_SBLOCK(7, W, SA, SB) M355_SBLOCK(8, W, SA, SB)                         \
-        M355_SBLOCK(9, W, SA, SB) M355_SBLOCK(10, W, SA, SB) M355_SBLOCK(11, W, SA, SB)                       \
-        /* sum the K-parts through LDS (two buffers in turn, so one barrier per item is enough) */            \
-        float4_t* rbuf = reinterpret_cast<float4_t*>(red + (round & 1) * RED1);                               \
-        round++;                                                                                              \
-        if (q > 0) {                                                                                          \
-            float4_t* dst = rbuf + ((size_t)(pl * (MOE_KPARTS - 1) + (q - 1)) * 64 + lane) * 2;               \
-            dst[0] = accA;                                                                                    \
-            dst[1] = accB;                                                                                    \
-        }                                                                                                     \
-        lds_barrier();                                                                                        \
-        if (q == 0 && live) {                                                                                 \
-            _Pragma("unroll") for (int qq = 0; qq < MOE_KPARTS - 1; qq++) {                                   \
-                const float4_t* src = rbuf + ((size_t)(pl * (MOE_KPARTS - 1) + qq) * 64 + lane) * 2;          \
-                accA += src[0];                                                                               \
-                accB += src[1];                                                                               \
-            }                                                                                                 \
-            if (n < mt) gemm_epilogue<MODE>(accA, accB, outp, pos0 + n, R, NP, p, g);                         \
-        }                                                                                                     \
+        // sum the K-parts through LDS (two buffers in turn, so one barrier per item is enough)
+        float4_t* rbuf = reinterpret_cast<float4_t*>(red + (round & (NRED - 1)) * RED1);
+        round++;
+        if (q > 0) {
+            float4_t* dst = rbuf + ((size_t)(pl * (MOE_KPARTS - 1) + (q - 1)) * 64 + lane) * 2;
+            dst[0] = accA;
+            dst[1] = accB;
+        }
+        lds_barrier();
+        if (q == 0 && live) {
+#pragma unroll
+            for (int qq = 0; qq < MOE_KPARTS - 1; qq++) {
+                const float4_t* src = rbuf + ((size_t)(pl * (MOE_KPARTS - 1) + qq) * 64 + lane) * 2;
+                accA += src[0];
+                accB += src[1];
+            }
+            if (n < mt) gemm_epilogue<MODE>(accA, accB, outp, pos0 + n, R, NP, p, g);
+        }
+        if (NRED == 1) lds_barrier();   // the single reduction buffer is rewritten by the next item
     }
-
-    for (int it = it0; it < it1; it += 2) {
-        M355_DO_ITEM(it, wA, sAa, sBa, wB, sAb, sBb)
-        if (it + 1 < it1) M355_DO_ITEM(it + 1, wB, sAb, sBb, wA, sAa, sBa)
-    }
-#undef M355_DO_ITEM
-#undef M355_SBLOCK
-#undef M355_LOAD_ITEM
+#undef M355_PLAIN
+#undef M355_STEP
+#undef M355_SCALE
+#undef M355_MFMA
+#undef M355_FETCH
+#undef M355_LOAD
+#undef M355_POINT_AT
 }
 
 // out[t][c] = sum over the token's local pairs, in k order.  FP16 mode rounds as the reference's fp16
@@ -519,6 +585,8 @@ static int device_setup(int dev, int* cus) {
         if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2>)) return rc;
         if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 1>)) return rc;
         if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 2>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 4>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 4>)) return rc;
         int v = 0;
         if (int rc = hip_status(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute")) return rc;
         ncu[d] = v > 0 ? v : 256;
@@ -529,7 +597,7 @@ static int device_setup(int dev, int* cus) {
 }
 
 static int stream_lds_bytes(int K, int mt_rows, int pairs) {
-    return LUT_BYTES + 2 * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4 + mt_rows * (K * 2 + XS_PAD);
+    return LUT_BYTES + (pairs >= 4 ? 1 : 2) * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4 + mt_rows * (K * 2 + XS_PAD);
 }
 
 // W [R][K] per expert.  K <= 48 blocks: streaming kernel, one or two workgroups per CU; else the general kernel.
@@ -540,7 +608,13 @@ static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, c
     if (NB <= MOE_KPARTS * MOE_CHUNK) {
         const int max_tiles = slots + ws.max_pairs / mt_rows;   // sum over experts of ceil(M_e / mt_rows) stays below this
         const int items2 = max_tiles * ((NP + 1) / 2);
-        if (items2 >= 2 * cus) {
+        if (items2 >= 2 * cus && getenv("M355_PAIRS4")) {
+            const int lds = stream_lds_bytes(K, mt_rows, 4);
+            const int items4 = max_tiles * ((NP + 3) / 4);
+            const int grid = items4 < cus ? items4 : cus;
+            moe_gemm_stream_kernel<MODE, 4><<<dim3(grid), dim3(1024), lds, st>>>(xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0,
+                                                                                 ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp);
+        } else if (items2 >= 2 * cus) {
             const int lds = stream_lds_bytes(K, mt_rows, 2);
             const int grid = items2 < cus ? items2 : cus;
             moe_gemm_stream_kernel<MODE, 2><<<dim3(grid), dim3(512), lds, st>>>(xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0,

@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmoe355.so")
+LIB_PATH = os.environ.get("M355_LIB_PATH") or os.path.join(_HERE, "libmoe355.so")
 
 ACT_SILU_CONCAT = 0
 FLAG_FP16_COMBINE = 1
