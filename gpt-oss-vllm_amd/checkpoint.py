@@ -1,0 +1,62 @@
+"""Reader for Unsloth / bitsandbytes NF4 expert tensors stored in safetensors shards.
+
+Key schema (patches/streaming_unsloth_bnb.py:118-146, patches/unsloth_direct_loader.py:68-82 of the reference):
+    model.layers.{L}.mlp.experts.{gate_up_projs|down_projs}.{E}.weight            packed uint8 [n/2, 1]
+    ...weight.absmax | .nested_absmax | .nested_quant_map | .quant_map            quantisation state
+The first shard that holds a key wins (streaming_unsloth_bnb.py:131-135); a key no shard holds yields None
+(:230).  Tensors are handed to the plug-in's weight_loader under their checkpoint names, exactly as vLLM's
+loader would, so a layer can be filled without vLLM.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Iterator, List, Optional, Tuple
+
+import torch
+
+PROJ_KEYS = {"gate_up": "gate_up_projs", "down": "down_projs"}
+STATE_SUFFIXES = ("absmax", "nested_absmax", "nested_quant_map", "quant_map")
+
+
+def expert_weight_key(layer_idx: int, expert_idx: int, proj: str) -> str:
+    return f"model.layers.{layer_idx}.mlp.experts.{PROJ_KEYS[proj]}.{expert_idx}.weight"
+
+
+def read_expert(checkpoint_paths: Iterable[str], layer_idx: int, expert_idx: int, proj: str
+                ) -> Optional[Dict[str, torch.Tensor]]:
+    """{'weight': uint8, 'absmax': ..., ...} of one expert matrix, or None if no shard has it."""
+    from safetensors import safe_open
+    key = expert_weight_key(layer_idx, expert_idx, proj)
+    for path in checkpoint_paths:
+        with safe_open(path, framework="pt", device="cpu") as f:
+            keys = set(f.keys())
+            if key not in keys:
+                continue
+            out = {"weight": f.get_tensor(key)}
+            for sfx in STATE_SUFFIXES:
+                if f"{key}.{sfx}" in keys:
+                    out[sfx] = f.get_tensor(f"{key}.{sfx}")
+            return out
+    return None
+
+
+def iter_layer_tensors(checkpoint_paths: List[str], layer_idx: int, num_experts: int
+                       ) -> Iterator[Tuple[str, torch.Tensor]]:
+    """(checkpoint name, tensor) pairs of every expert tensor of one layer, in expert order."""
+    for e in range(num_experts):
+        for proj in ("gate_up", "down"):
+            t = read_expert(checkpoint_paths, layer_idx, e, proj)
+            if t is None:
+                raise KeyError(f"{expert_weight_key(layer_idx, e, proj)} is in none of the shards")
+            key = expert_weight_key(layer_idx, e, proj)
+            yield key, t["weight"]
+            for sfx in STATE_SUFFIXES:
+                if sfx in t:
+                    yield f"{key}.{sfx}", t[sfx]
+
+
+def load_layer(method, layer, checkpoint_paths: List[str], layer_idx: int) -> None:
+    """Fill one FusedMoE layer (already through method.create_weights) from the shards and convert it."""
+    E = layer._m355_dims[0]
+    for name, tensor in iter_layer_tensors(checkpoint_paths, layer_idx, E):
+        method.weight_loader(layer, None, tensor, name, shard_id=None, expert_id=None)
+    method.process_weights_after_loading(layer)

@@ -1,0 +1,273 @@
+"""vLLM quantization plug-in surface for the MI355X NF4 MoE path.
+
+Mirrors the interface the reference occupies with patches/bnb_moe_4bit.py (a QuantizationConfig
+subclass injected per layer as FusedMoE(quant_config=...), patches/patch_6_add_bnb_moe.py:78-105) and with
+the FusedMoE.weight_loader hook of patches/patch_9_fusedmoe_unsloth.py:24-51 -- same method names,
+argument meaning and return conventions -- but hands the work to libmoe355.so instead of bitsandbytes.
+
+vLLM is optional at import time: when it is installed the classes derive from its base classes and
+`register()` adds the method under the name "mi355_nf4_moe"; when it is not, duck-typed bases let the
+same classes be driven directly (tests, bench).  Nothing here falls back to a CPU or eager path: the
+forward raises if the HIP library or the GPU is missing.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import torch
+
+from . import lib
+
+try:  # pragma: no cover - exercised only where vLLM is installed
+    from vllm.model_executor.layers.quantization.base_config import QuantizationConfig as _QConfigBase
+    from vllm.model_executor.layers.fused_moe.layer import FusedMoEMethodBase as _MoEMethodBase
+    HAS_VLLM = True
+except Exception:  # vLLM absent (or its import chain unusable): same surface, plain bases
+    HAS_VLLM = False
+
+    class _QConfigBase:  # type: ignore[no-redef]
+        def __init__(self):
+            self.packed_modules_mapping: Dict[str, List[str]] = {}
+
+    class _MoEMethodBase:  # type: ignore[no-redef]
+        def __init__(self, *args, **kwargs):
+            pass
+
+QUANT_NAME = "mi355_nf4_moe"
+BLOCKSIZE = 64   # bitsandbytes' default NF4 block; the reference never passes another (streaming_unsloth_bnb.py:36-44)
+
+
+# ---------------------------------------------------------------------------------------------
+# absmax un-double-quantisation, exactly the reference's torch expressions (host, load time)
+# ---------------------------------------------------------------------------------------------
+def resolve_absmax(absmax: Optional[torch.Tensor], nested_absmax: Optional[torch.Tensor],
+                   nested_quant_map: Optional[torch.Tensor]) -> torch.Tensor:
+    """fp32 absmax per block by the rules of patches/streaming_unsloth_bnb.py:148-173, computed with the
+    same torch CPU operations (so the fp32 mean of nested_absmax is the reference's own value)."""
+    if nested_absmax is not None:
+        if nested_quant_map is None or absmax is None:
+            raise ValueError("nested_absmax needs absmax (uint8) and nested_quant_map")
+        na = nested_absmax.detach().cpu().float()
+        nm = nested_quant_map.detach().cpu().float()
+        a = nm[absmax.detach().cpu().to(torch.uint8).long()]
+        if na.numel() == 1:
+            return a * na.item()
+        if na.shape == a.shape:
+            return a * na
+        try:
+            return a * na
+        except RuntimeError:
+            return a * na.mean()     # the branch real checkpoints take (:165-171)
+    if absmax is None:
+        return torch.ones(1)
+    return absmax.detach().cpu().float()
+
+
+# ---------------------------------------------------------------------------------------------
+# QuantizationConfig
+# ---------------------------------------------------------------------------------------------
+class Mi355Nf4MoEConfig(_QConfigBase):
+    """4-bit NF4 for the MoE experts only; router and attention stay fp16 (patches/bnb_moe_4bit.py:22-56)."""
+
+    def __init__(self):
+        super().__init__()
+        self.weight_bits = 4
+        self.group_size = BLOCKSIZE
+        self.compute_dtype = torch.float16
+        self.use_nf4 = True
+
+    @classmethod
+    def get_name(cls) -> str:
+        return QUANT_NAME
+
+    @classmethod
+    def get_supported_act_dtypes(cls) -> List[torch.dtype]:
+        return [torch.float16, torch.bfloat16]
+
+    @classmethod
+    def get_min_capability(cls) -> int:
+        return 70   # same figure as the reference (:53-56); gfx950 reports 9.5
+
+    @staticmethod
+    def get_config_filenames() -> List[str]:
+        return []
+
+    @classmethod
+    def from_config(cls, config: Dict[str, Any]) -> "Mi355Nf4MoEConfig":
+        return cls()
+
+    def get_scaled_act_names(self) -> List[str]:
+        return []
+
+    def get_quant_method(self, layer, prefix: str):
+        """The method object for expert layers, None for everything else (router, attention stay fp16).
+        The reference answers with the string "bnb_4bit" for prefixes that name experts (:43-48); FusedMoE
+        needs an object with create_weights/apply, which is what is returned here."""
+        if "experts" in prefix:
+            return Mi355Nf4MoEMethod(self)
+        return None
+
+
+def is_moe_weight(name: str) -> bool:
+    """patches/bnb_moe_4bit.py:99-109 plus the Unsloth per-expert names of patch_9."""
+    pats = ("experts.w13_weight", "experts.w2_weight", "experts.w13_bias", "experts.w2_bias", "gate_up_proj",
+            "down_proj")
+    return any(p in name for p in pats)
+
+
+def get_moe_weight_names(model) -> List[str]:
+    return [n for n, _ in model.named_parameters() if is_moe_weight(n)]
+
+
+# ---------------------------------------------------------------------------------------------
+# FusedMoE method
+# ---------------------------------------------------------------------------------------------
+_SUFFIXES = ("nested_quant_map", "nested_absmax", "quant_map", "absmax")
+
+
+class Mi355Nf4MoEMethod(_MoEMethodBase):
+    """create_weights / weight_loader / process_weights_after_loading / apply for a FusedMoE layer."""
+
+    def __init__(self, quant_config: Mi355Nf4MoEConfig, moe=None):
+        try:
+            super().__init__(moe)
+        except TypeError:
+            super().__init__()
+        self.quant_config = quant_config
+
+    # -- weights -------------------------------------------------------------------------------
+    def create_weights(self, layer, num_experts: int, hidden_size: int, intermediate_size_per_partition: int,
+                       params_dtype: torch.dtype = torch.float16, **extra_weight_attrs):
+        E, H, FF = num_experts, hidden_size, intermediate_size_per_partition
+        if H % 64 or FF % 64:
+            raise ValueError(f"hidden_size {H} and intermediate_size {FF} must be multiples of 64")
+        dev = extra_weight_attrs.pop("device", None)
+
+        def param(shape, dtype):
+            p = torch.nn.Parameter(torch.empty(shape, dtype=dtype, device=dev), requires_grad=False)
+            p.weight_loader = lambda *a, **k: self.weight_loader(layer, p, *a, **k)
+            for key, val in extra_weight_attrs.items():
+                if key != "weight_loader":
+                    setattr(p, key, val)
+            return p
+
+        specs = {"w13_qweight": ((E, FF * H), torch.uint8), "w13_absmax": ((E, 2 * FF * H // BLOCKSIZE), torch.float32),
+                 "w2_qweight": ((E, H * FF // 2), torch.uint8), "w2_absmax": ((E, H * FF // BLOCKSIZE), torch.float32)}
+        for name, (shape, dtype) in specs.items():
+            p = param(shape, dtype)
+            if isinstance(layer, torch.nn.Module):
+                layer.register_parameter(name, p)
+            else:
+                setattr(layer, name, p)
+        layer._m355_dims = (E, H, FF)
+        layer._m355_raw = {}          # (expert, "gate_up_projs"|"down_projs") -> {"weight"| suffix: tensor}
+        layer._m355_ready = False
+        layer._m355_ws = {}
+
+    def weight_loader(self, layer, param, loaded_weight: torch.Tensor, weight_name: str, shard_id=None,
+                      expert_id=None, return_success: bool = False):
+        """Same contract as the hook patches/patch_9_fusedmoe_unsloth.py:24-51 puts into FusedMoE.weight_loader:
+        names holding 'gate_up_projs' / 'down_projs' are parsed as
+        model.layers.L.mlp.experts.<proj>.E.weight[.suffix]; the packed tensor is kept as loaded and converted
+        later; returns `True if return_success else None`."""
+        if "gate_up_projs" not in weight_name and "down_projs" not in weight_name:
+            raise ValueError(f"not an Unsloth per-expert MoE tensor: {weight_name}")
+        parts = weight_name.split(".")
+        if len(parts) < 7:
+            raise ValueError(f"cannot parse expert index from {weight_name}")
+        expert_idx = int(parts[6])       # patch_9:35
+        proj_type = parts[5]             # patch_9:36
+        suffix = "weight"
+        for sfx in _SUFFIXES:
+            if weight_name.endswith("." + sfx):
+                suffix = sfx
+                break
+        layer._m355_raw.setdefault((expert_idx, proj_type), {})[suffix] = loaded_weight
+        layer._m355_ready = False
+        return True if return_success else None
+
+    def process_weights_after_loading(self, layer) -> None:
+        """Resolve each expert's absmax (reference rules), move the packed blocks to the GPU unchanged and
+        repack them into the kernels' tile order.  Nothing is re-quantised (the reference re-quantises through
+        bitsandbytes when it moves an expert to the GPU, streaming_unsloth_bnb.py:48-65)."""
+        E, H, FF = layer._m355_dims
+        dev = layer.w13_qweight.device
+        if dev.type != "cuda":
+            raise lib.Mi355LibraryError("expert weights must live on the GPU before process_weights_after_loading")
+        for (e, proj), t in sorted(layer._m355_raw.items()):
+            if not (0 <= e < E) or "weight" not in t:
+                raise ValueError(f"incomplete or out-of-range expert tensor ({e}, {proj})")
+            rows, cols = (2 * FF, H) if proj == "gate_up_projs" else (H, FF)
+            q = t["weight"].reshape(-1).to(torch.uint8)
+            if q.numel() * 2 != rows * cols:
+                raise ValueError(f"expert {e} {proj}: {q.numel()} packed bytes, expected {rows * cols // 2}")
+            am = resolve_absmax(t.get("absmax"), t.get("nested_absmax"), t.get("nested_quant_map")).reshape(-1)
+            if am.numel() * BLOCKSIZE != rows * cols:
+                raise ValueError(f"expert {e} {proj}: {am.numel()} absmax entries, the kernels need one per {BLOCKSIZE}")
+            qt, at = lib.repack_nf4(q.to(dev).contiguous(), am.float().to(dev).contiguous(), rows, cols)
+            if proj == "gate_up_projs":
+                layer.w13_qweight.data[e], layer.w13_absmax.data[e] = qt, at
+            else:
+                layer.w2_qweight.data[e], layer.w2_absmax.data[e] = qt, at
+        layer._m355_raw = {}
+        layer._m355_ready = True
+
+    # -- forward -------------------------------------------------------------------------------
+    def apply(self, layer, x: torch.Tensor, router_logits: torch.Tensor, top_k: int, renormalize: bool = True,
+              use_grouped_topk: bool = False, topk_group=None, num_expert_group=None, global_num_experts: int = -1,
+              expert_map: Optional[torch.Tensor] = None, custom_routing_function=None, scoring_func: str = "softmax",
+              e_score_correction_bias=None, apply_router_weight_on_input: bool = False, activation: str = "silu",
+              **kwargs) -> torch.Tensor:
+        """FusedMoE forward: top-k + softmax over the selected logits, the routed experts, the weighted sum --
+        the semantics of patches/unsloth_to_vllm_converter.py:282-325."""
+        if not layer._m355_ready:
+            raise RuntimeError("process_weights_after_loading has not run for this layer")
+        if not renormalize or use_grouped_topk or custom_routing_function is not None or scoring_func != "softmax" \
+                or e_score_correction_bias is not None or apply_router_weight_on_input:
+            raise NotImplementedError("only top-k followed by softmax over the selected logits is implemented")
+        if activation != "silu":
+            raise NotImplementedError(f"activation {activation!r}: only silu(gate)*up over concatenated halves")
+        E, H, FF = layer._m355_dims
+        shape = x.shape
+        x2 = x.reshape(-1, H)
+        in_dtype = x2.dtype
+        if in_dtype != torch.float16:
+            x2 = x2.to(torch.float16)
+        lg = router_logits.reshape(-1, router_logits.shape[-1])
+        if lg.dtype != torch.float16:
+            lg = lg.to(torch.float16)
+        ids, w = lib.topk_softmax(lg.contiguous(), top_k)
+        e_first = 0
+        if expert_map is not None:   # vLLM expert parallelism: map[global id] = local id or -1, contiguous shard
+            owned = torch.nonzero(expert_map >= 0).flatten()
+            e_first = int(owned[0].item()) if owned.numel() else 0
+        T = x2.shape[0]
+        ws = layer._m355_ws.get(T)
+        if ws is None:
+            ws = torch.empty(max(256, lib.moe_workspace_bytes(T, top_k, H, FF, E)), dtype=torch.uint8, device=x2.device)
+            layer._m355_ws = {T: ws}
+        out = lib.moe_nf4_forward(x2.contiguous(), ids, w, layer.w13_qweight.data, layer.w13_absmax.data,
+                                  layer.w2_qweight.data, layer.w2_absmax.data, E_local=E, e_first=e_first, H=H, FF=FF,
+                                  workspace=ws)
+        if in_dtype != torch.float16:
+            out = out.to(in_dtype)
+        return out.reshape(shape)
+
+
+def cast_router_to_fp16(mlp_block) -> None:
+    """What patches/monkey_patch_router_fp16.py:6-17 does after MLPBlock.__init__: the router nn.Linear runs in
+    fp16 so its logits match the fp16 expert path."""
+    router = getattr(mlp_block, "router", None)
+    if isinstance(router, torch.nn.Linear) and router.weight.dtype != torch.float16:
+        with torch.no_grad():
+            router.to(dtype=torch.float16)
+
+
+def register() -> bool:
+    """Register the config with vLLM under QUANT_NAME (a `vllm.general_plugins` entry point may call this).
+    Returns False when vLLM is not installed; site-packages is never edited."""
+    if not HAS_VLLM:
+        return False
+    from vllm.model_executor.layers.quantization import register_quantization_config  # pragma: no cover
+    register_quantization_config(QUANT_NAME)(Mi355Nf4MoEConfig)  # pragma: no cover
+    return True  # pragma: no cover

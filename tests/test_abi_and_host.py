@@ -1,0 +1,123 @@
+"""CPU: the C-ABI library loads and exports what include/m355.h declares; host-side plug-in logic."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(m355):
+    header = open(os.path.join(ROOT, "include", "m355.h")).read()
+    declared = set(re.findall(r"M355_API\s+[\w\s\*]+?\b(m355_\w+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    assert declared == set(m355.EXPORTS)
+    L = m355.load()
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert m355.version() >= 100
+    assert m355.ep_row_bytes(2880, 4) == 5792
+    assert m355.moe_workspace_bytes(32, 4, 2880, 2880, 32) > 32 * 4 * 2880 * 2 * 2
+
+
+def test_no_cpu_fallback(m355):
+    q = torch.zeros(64, dtype=torch.uint8)
+    a = torch.ones(2, dtype=torch.float32)
+    with pytest.raises(m355.Mi355LibraryError, match="GPU tensor"):
+        m355.nf4_dequant(q, a)
+    from gpt_oss_vllm_amd import plugin
+    cfg = plugin.Mi355Nf4MoEConfig()
+    m = cfg.get_quant_method(None, "model.layers.0.mlp.experts")
+    layer = torch.nn.Module()
+    m.create_weights(layer, 2, 64, 64, torch.float16)
+    with pytest.raises(m355.Mi355LibraryError):
+        m.process_weights_after_loading(layer)     # CPU layer: refuse instead of computing on the host
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    import importlib
+    import gpt_oss_vllm_amd  # noqa: F401
+    from gpt_oss_vllm_amd import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(lib.Mi355LibraryError, match="missing"):
+        lib.load()
+
+
+def test_config_surface_mirrors_reference():
+    from gpt_oss_vllm_amd import plugin
+    cfg = plugin.Mi355Nf4MoEConfig.from_config({})
+    assert cfg.get_name() == "mi355_nf4_moe"
+    assert cfg.weight_bits == 4 and cfg.use_nf4 and cfg.compute_dtype == torch.float16
+    assert cfg.get_supported_act_dtypes() == [torch.float16, torch.bfloat16]
+    assert cfg.get_min_capability() == 70
+    assert cfg.get_config_filenames() == [] and cfg.get_scaled_act_names() == []
+    assert cfg.get_quant_method(None, "model.layers.3.attn.qkv") is None          # attention stays fp16
+    assert cfg.get_quant_method(None, "model.layers.3.mlp.router") is None        # router stays fp16
+    assert isinstance(cfg.get_quant_method(None, "model.layers.3.mlp.experts"), plugin.Mi355Nf4MoEMethod)
+    assert plugin.is_moe_weight("model.layers.0.mlp.experts.w13_weight")
+    assert plugin.is_moe_weight("model.layers.0.mlp.experts.gate_up_projs.3.weight")
+    assert not plugin.is_moe_weight("model.layers.0.attn.qkv.weight")
+
+
+def test_weight_loader_hook_contract():
+    from gpt_oss_vllm_amd import plugin
+    m = plugin.Mi355Nf4MoEMethod(plugin.Mi355Nf4MoEConfig())
+    layer = torch.nn.Module()
+    m.create_weights(layer, 4, 64, 64, torch.float16)
+    assert tuple(layer.w13_qweight.shape) == (4, 64 * 64) and layer.w13_qweight.dtype == torch.uint8
+    assert tuple(layer.w2_absmax.shape) == (4, 64)
+    t = torch.zeros(8, dtype=torch.uint8)
+    name = "model.layers.7.mlp.experts.gate_up_projs.3.weight"
+    assert m.weight_loader(layer, None, t, name, None, None, return_success=True) is True
+    assert m.weight_loader(layer, None, t, name + ".absmax", None, None) is None
+    assert layer.w13_qweight.weight_loader(t, "model.layers.7.mlp.experts.down_projs.1.weight.nested_absmax", None, None,
+                                           return_success=True) is True
+    assert set(layer._m355_raw) == {(3, "gate_up_projs"), (1, "down_projs")}
+    assert set(layer._m355_raw[(3, "gate_up_projs")]) == {"weight", "absmax"}
+    assert "nested_absmax" in layer._m355_raw[(1, "down_projs")]
+    with pytest.raises(ValueError):
+        m.weight_loader(layer, None, t, "model.layers.7.mlp.experts.w13_weight", None, None)
+    with pytest.raises(RuntimeError):
+        m.apply(layer, torch.zeros(1, 64), torch.zeros(1, 4), top_k=2)
+
+
+@pytest.mark.parametrize("name", ["down_nested_mean", "down_nested_scalar", "down_nested_elementwise",
+                                  "down_absmax_f32", "down_absmax_u8_plain", "down_no_absmax"])
+def test_host_absmax_resolution_equals_oracle(name, ref):
+    from gpt_oss_vllm_amd import plugin
+    c = ref.golden_dequant_case(name)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    got = plugin.resolve_absmax(t(c["absmax"]), t(c["nested_absmax"]), t(c["nested_map"])).numpy().astype(np.float32)
+    want = ref.resolve_absmax(c["absmax"], c["nested_map"], c["nested_absmax"])
+    assert np.array_equal(got.view(np.uint32).reshape(-1), want.view(np.uint32).reshape(-1))
+
+
+def test_checkpoint_reader_schema(tmp_path, ref):
+    from safetensors.torch import save_file
+    from gpt_oss_vllm_amd import checkpoint
+    k = checkpoint.expert_weight_key(3, 5, "down")
+    assert k == "model.layers.3.mlp.experts.down_projs.5.weight"
+    a, b = str(tmp_path / "a.safetensors"), str(tmp_path / "b.safetensors")
+    save_file({"unrelated": torch.zeros(1)}, a)
+    save_file({k: torch.arange(16, dtype=torch.uint8).reshape(-1, 1), k + ".absmax": torch.ones(4, dtype=torch.uint8),
+               k + ".nested_absmax": torch.ones(1), k + ".nested_quant_map": torch.linspace(0, 1, 256)}, b)
+    t = checkpoint.read_expert([a, b], 3, 5, "down")           # first shard lacks the key -> second is used
+    assert set(t) == {"weight", "absmax", "nested_absmax", "nested_quant_map"}
+    assert checkpoint.read_expert([a], 3, 5, "down") is None    # nowhere -> None, as the reference returns
+    assert checkpoint.read_expert([a, b], 3, 5, "gate_up") is None
+    with pytest.raises(KeyError):
+        list(checkpoint.iter_layer_tensors([a, b], 3, 1))
+
+
+def test_router_cast_helper():
+    from gpt_oss_vllm_amd import plugin
+
+    class Block:
+        pass
+    blk = Block()
+    blk.router = torch.nn.Linear(8, 4).to(torch.bfloat16)
+    plugin.cast_router_to_fp16(blk)
+    assert blk.router.weight.dtype == torch.float16 and blk.router.bias.dtype == torch.float16

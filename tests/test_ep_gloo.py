@@ -1,0 +1,105 @@
+"""CPU, world_size 2 over gloo: the expert-parallel exchange (pack -> all-to-all -> experts -> all-to-all ->
+reduce) with CPU stand-ins for the device kernels, checked against the unsharded oracle forward."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+H, FF, E, K, T = 128, 64, 8, 2, 5
+
+
+class CpuOps:
+    """numpy restatements of m355_ep_pack / unpack / reduce and the oracle as the local expert compute."""
+
+    def __init__(self, ref, layer_np):
+        self.ref, self.layer = ref, layer_np
+
+    def row_bytes(self, H_, k):
+        return (2 * H_ + 8 * k + 15) // 16 * 16
+
+    def workspace_bytes(self, *a):
+        return 0
+
+    def pack(self, x, ids, w, n_ranks, epr, send):
+        T_, k = ids.shape
+        rb = self.row_bytes(x.shape[1], k)
+        buf = send.numpy().reshape(n_ranks, T_, rb)
+        for r in range(n_ranks):
+            for t in range(T_):
+                hit = ((ids[t] >= r * epr) & (ids[t] < (r + 1) * epr)).any()
+                row = buf[r, t]
+                if hit:
+                    row[:2 * H] = x[t].numpy().view(np.uint8)
+                    row[2 * H:2 * H + 4 * k] = ids[t].numpy().view(np.uint8)
+                    row[2 * H + 4 * k:2 * H + 8 * k] = w[t].numpy().view(np.uint8)
+                else:
+                    row[2 * H:2 * H + 4 * k] = np.full(k, -1, np.int32).view(np.uint8)
+
+    def unpack(self, recv, NT, k, H_, x_all, ids_all, w_all):
+        rb = self.row_bytes(H_, k)
+        buf = recv.numpy().reshape(NT, rb)
+        for t in range(NT):
+            ids = buf[t, 2 * H_:2 * H_ + 4 * k].copy().view(np.int32)
+            if ids[0] >= 0:
+                x_all[t] = torch.from_numpy(buf[t, :2 * H_].copy().view(np.float16))
+                ids_all[t] = torch.from_numpy(ids.copy())
+                w_all[t] = torch.from_numpy(buf[t, 2 * H_ + 4 * k:2 * H_ + 8 * k].copy().view(np.float32))
+            else:
+                ids_all[t] = -1
+                w_all[t] = 0
+
+    def moe(self, x, ids, w, weights, E_local, e_first, H_, FF_, workspace, out, flags):
+        sl = slice(e_first, e_first + E_local)
+        o = self.ref.moe_forward(x.numpy(), np.where(ids.numpy() < 0, 10 ** 6, ids.numpy()).astype(np.int32), w.numpy(),
+                                 w13_q=self.layer["w13_q"][sl], w13_absmax=self.layer["w13_absmax"][sl],
+                                 w2_q=self.layer["w2_q"][sl], w2_absmax=self.layer["w2_absmax"][sl], E_local=E_local,
+                                 e_first=e_first, H=H_, FF=FF_, flags=flags)
+        out.copy_(torch.from_numpy(o))
+
+    def reduce(self, recv, n_ranks, T_, H_, out):
+        out.copy_(recv.reshape(n_ranks, T_, H_).float().sum(0).half())
+
+
+def _worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import ref
+    import gpt_oss_vllm_amd  # noqa: F401
+    from gpt_oss_vllm_amd import ep
+    layer = ref.synth_layer(77, E, H, FF)
+    x = ref.normal_f16(ref.stream_seed(100, rank), (T, H))
+    lg = ref.normal_f16(ref.stream_seed(200, rank), (T, E), 1.5)
+    ids, w, _ = ref.router_topk(lg, np.eye(E, dtype=np.float16), None, K)
+    moe = ep.ExpertParallelMoE(None, num_experts=E, top_k=K, hidden=H, ffn=FF, max_tokens=T, ops=CpuOps(ref, layer),
+                               device=torch.device("cpu"), flags=0)
+    assert (moe.epr, moe.e_first) == (E // world, rank * (E // world))
+    out = moe.forward(torch.from_numpy(x), torch.from_numpy(ids), torch.from_numpy(w))
+    want = ref.moe_forward(x, ids, w, **layer, E_local=E, H=H, FF=FF, flags=0).astype(np.float32)
+    err = float(np.abs(out.float().numpy() - want).max())
+    q.put((rank, err, float(np.abs(want).max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_expert_parallel_exchange_world2():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, mx in res:
+        assert err <= 2e-3 * mx + 1e-6, (rank, err, mx)

@@ -231,3 +231,100 @@ def test_paged_attention_vs_oracle(ctx, ref, m355, cuda):
                                  _to_dev(cl, cuda), max_ctx=max_ctx, scale=scale)
     torch.cuda.synchronize()
     _close(out.cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_ep_pack_unpack_reduce_kernels(ref, m355, cuda):
+    H, k, T, N, epr = 256, 3, 7, 4, 2
+    sd = ref.stream_seed(555)
+    x = ref.normal_f16(ref.stream_seed(sd, 1), (T, H))
+    lg = ref.normal_f16(ref.stream_seed(sd, 2), (T, N * epr))
+    ids, w, _ = ref.router_topk(lg, np.eye(N * epr, dtype=np.float16), None, k)
+    rb = m355.ep_row_bytes(H, k)
+    assert rb == (2 * H + 8 * k + 15) // 16 * 16
+    send = torch.zeros(N * T * rb, dtype=torch.uint8, device=cuda)
+    m355.ep_pack(_to_dev(x, cuda), _to_dev(ids, cuda), _to_dev(w, cuda), N, epr, send)
+    buf = send.cpu().numpy().reshape(N, T, rb)
+    for r in range(N):
+        for t in range(T):
+            got_ids = buf[r, t, 2 * H:2 * H + 4 * k].copy().view(np.int32)
+            if ((ids[t] >= r * epr) & (ids[t] < (r + 1) * epr)).any():
+                assert np.array_equal(buf[r, t, :2 * H].copy().view(np.float16).view(np.uint16), x[t].view(np.uint16))
+                assert np.array_equal(got_ids, ids[t])
+                assert np.array_equal(buf[r, t, 2 * H + 4 * k:2 * H + 8 * k].copy().view(np.float32), w[t])
+            else:
+                assert (got_ids == -1).all()
+    # unpack what rank 1 would receive if every peer sent it this rank's chunk 1
+    recv = send.reshape(N, T * rb)[1].repeat(N).contiguous()
+    x_all = torch.zeros((N * T, H), dtype=torch.float16, device=cuda)
+    ids_all = torch.zeros((N * T, k), dtype=torch.int32, device=cuda)
+    w_all = torch.zeros((N * T, k), dtype=torch.float32, device=cuda)
+    m355.ep_unpack(recv, N * T, k, H, x_all, ids_all, w_all)
+    ids_all, x_all = ids_all.cpu().numpy(), x_all.cpu().numpy()
+    for t in range(T):
+        hit = ((ids[t] >= epr) & (ids[t] < 2 * epr)).any()
+        for s in range(N):
+            if hit:
+                assert np.array_equal(ids_all[s * T + t], ids[t])
+                assert np.array_equal(x_all[s * T + t].view(np.uint16), x[t].view(np.uint16))
+            else:
+                assert (ids_all[s * T + t] == -1).all()
+    parts = ref.normal_f16(ref.stream_seed(sd, 3), (N, T, H))
+    out = torch.empty((T, H), dtype=torch.float16, device=cuda)
+    m355.ep_reduce(_to_dev(parts, cuda), N, T, H, out)
+    want = parts.astype(np.float32).sum(0).astype(np.float16)
+    assert np.abs(out.cpu().numpy().astype(np.float32) - want.astype(np.float32)).max() <= 2e-3 * np.abs(want).max()
+
+
+def test_plugin_path_end_to_end(ref, m355, cuda, tmp_path):
+    """config -> method -> create_weights -> weight_loader (names as in the checkpoint, double-quantised state)
+    -> process_weights_after_loading -> apply, from a safetensors shard in the Unsloth key schema."""
+    from safetensors.torch import save_file
+    from gpt_oss_vllm_amd import checkpoint, plugin
+    H, FF, E, k, T = 256, 192, 4, 2, 9
+    tensors, layer_ref = {}, dict(w13_q=[], w13_absmax=[], w2_q=[], w2_absmax=[])
+    for e in range(E):
+        for proj, n, tag in (("gate_up", 2 * FF * H, "w13"), ("down", H * FF, "w2")):
+            q, a8, na, nm = ref.synth_expert_tensor(ref.stream_seed(9, e, n), n)
+            key = checkpoint.expert_weight_key(2, e, proj)
+            tensors[key] = torch.from_numpy(q.copy()).reshape(-1, 1)
+            tensors[key + ".absmax"] = torch.from_numpy(a8.copy())
+            tensors[key + ".nested_absmax"] = torch.from_numpy(na.copy())
+            tensors[key + ".nested_quant_map"] = torch.from_numpy(nm.copy())
+            layer_ref[tag + "_q"].append(q)
+            layer_ref[tag + "_absmax"].append(ref.resolve_absmax(a8, nm, na))
+    layer_ref = {n: np.stack(v) for n, v in layer_ref.items()}
+    shard = str(tmp_path / "model-00001.safetensors")
+    save_file(tensors, shard)
+    cfg = plugin.Mi355Nf4MoEConfig()
+    method = cfg.get_quant_method(None, "model.layers.2.mlp.experts")
+    layer = torch.nn.Module()
+    method.create_weights(layer, E, H, FF, torch.float16, device=cuda)
+    checkpoint.load_layer(method, layer, [shard], 2)
+    x = ref.normal_f16(ref.stream_seed(9, 100), (T, H))
+    lg = ref.normal_f16(ref.stream_seed(9, 101), (T, E), 1.5)
+    out = method.apply(layer, _to_dev(x, cuda), _to_dev(lg, cuda), top_k=k, renormalize=True)
+    ids, w, _ = ref.router_topk(lg, np.eye(E, dtype=np.float16), None, k)
+    want = ref.moe_forward(x, ids, w, **layer_ref, E_local=E, H=H, FF=FF)
+    _close(out.cpu().numpy(), want)
+    # bf16 activations are accepted (converted at the boundary) and come back as bf16
+    out_bf = method.apply(layer, _to_dev(x, cuda).to(torch.bfloat16), _to_dev(lg, cuda), top_k=k, renormalize=True)
+    assert out_bf.dtype == torch.bfloat16
+    with pytest.raises(NotImplementedError):
+        method.apply(layer, _to_dev(x, cuda), _to_dev(lg, cuda), top_k=k, renormalize=False)
+
+
+def test_expert_parallel_class_single_rank(ref, m355, cuda):
+    from gpt_oss_vllm_amd import ep
+    H, FF, E, k, T = 256, 192, 6, 2, 5
+    layer = ref.synth_layer(321, E, H, FF)
+    tl = tiled_layer(m355, layer, E, H, FF, cuda)
+    x = ref.normal_f16(322, (T, H))
+    lg = ref.normal_f16(323, (T, E))
+    ids, w, _ = ref.router_topk(lg, np.eye(E, dtype=np.float16), None, k)
+    moe = ep.ExpertParallelMoE(tl, num_experts=E, top_k=k, hidden=H, ffn=FF, max_tokens=T)
+    out = moe.forward(_to_dev(x, cuda), _to_dev(ids, cuda), _to_dev(w, cuda))
+    want = ref.moe_forward(x, ids, w, **layer, E_local=E, H=H, FF=FF)
+    _close(out.cpu().numpy(), want)
+    with pytest.raises(ValueError):
+        moe.forward(_to_dev(x[:2], cuda), _to_dev(ids[:2], cuda), _to_dev(w[:2], cuda))

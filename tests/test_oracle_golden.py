@@ -1,0 +1,136 @@
+"""CPU: pin the oracle (C restatement + numpy twin) against the golden outputs of the reference's own Python."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _gold():
+    return json.load(open(os.path.join(GOLD, "dequant_golden.json")))
+
+
+def test_nf4_table_matches_reference(ref):
+    bits = np.array(_gold()["nf4_table_bits"], dtype=np.uint32)
+    assert np.array_equal(ref.NF4_QUANT_MAP.view(np.uint32), bits)
+    import ctypes
+    L = ref.lib()
+    L.m355_ref_nf4_table.restype = ctypes.POINTER(ctypes.c_float)
+    c = np.array([L.m355_ref_nf4_table()[i] for i in range(16)], dtype=np.float32)
+    assert np.array_equal(c.view(np.uint32), bits)
+
+
+@pytest.mark.parametrize("name", ["gate_up_nested_mean", "down_nested_mean", "down_nested_scalar",
+                                  "down_nested_elementwise", "down_absmax_f32", "down_absmax_u8_plain",
+                                  "down_no_absmax", "gate_up_absmax_single", "down_absmax_bs128", "down_ragged_plus1",
+                                  "down_ragged_bs128", "down_ragged_short"])
+def test_dequant_bit_exact_vs_reference(name, ref):
+    g = _gold()["cases"][name]
+    case = ref.golden_dequant_case(name)
+    out = ref.golden_dequant_oracle(case).view(np.uint16)
+    assert list(g["shape"]) == ([5760, 2880] if case["proj"] == "gate_up" else [2880, 2880])
+    assert out.size == g["shape"][0] * g["shape"][1]
+    assert hashlib.sha256(out.tobytes()).hexdigest() == g["sha256"]
+    pos = np.array(g["sample_pos"])
+    assert np.array_equal(out[pos], np.array(g["sample_bits"], dtype=np.uint16))
+
+
+@pytest.mark.parametrize("name", ["down_nested_mean", "down_ragged_short", "down_absmax_bs128", "gate_up_absmax_single"])
+def test_numpy_twin_equals_c(name, ref):
+    case = ref.golden_dequant_case(name)
+    a = ref.resolve_absmax(case["absmax"], case["nested_map"], case["nested_absmax"])
+    c = ref.nf4_dequant(case["q"], case["n_params"], a).view(np.uint16)
+    n = ref.nf4_dequant_numpy(case["q"], case["n_params"], a).view(np.uint16)
+    assert np.array_equal(c, n)
+
+
+def test_missing_key_is_none_in_reference():
+    assert _gold()["missing_returns_none"] is True
+
+
+def test_fp16_conversions_exhaustive(ref):
+    L = ref.lib()
+    halves = np.arange(65536, dtype=np.uint16)
+    f = halves.view(np.float16).astype(np.float32)
+    for h in list(range(0, 65536, 97)) + [0, 1, 0x3ff, 0x400, 0x7bff, 0x7c00, 0x8000, 0xfbff, 0xfc00]:
+        v = L.m355_ref_f16_to_f32(h)
+        if np.isnan(f[h]):
+            assert np.isnan(v)
+        else:
+            assert v == f[h]
+            assert L.m355_ref_f32_to_f16(float(f[h])) == h
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.normal(size=2000), rng.normal(size=2000) * 1e-6, rng.normal(size=500) * 7e4,
+                        [65504.0, 65519.9, 65520.0, 2.0 ** -25, 2.0 ** -25 * 1.0001, 2.0 ** -24 * 1.5]]).astype(np.float32)
+    want = x.astype(np.float16).view(np.uint16)
+    got = np.array([L.m355_ref_f32_to_f16(float(v)) for v in x], dtype=np.uint16)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("name", ["fwd_full_T1", "fwd_full_T3", "fwd_small_T37"])
+def test_forward_vs_reference(name, ref):
+    """The reference's UnslothMoEWrapper.forward on fp16 nn.Linear experts; the oracle accumulates each dot
+    product in fp32 in another order, so outputs may differ by an fp16 rounding: |d| <= 2 ulp(fp16) of max|y|."""
+    c = ref.golden_forward_case(name)
+    ids = np.load(os.path.join(GOLD, name + ".topk_ids.npy"))
+    w = np.load(os.path.join(GOLD, name + ".topk_w.npy")).astype(np.float32)
+    want = np.load(os.path.join(GOLD, name + ".out.npy")).astype(np.float32)
+    got = ref.moe_forward(c["x"], ids, w, w13_q=c["w13_q"], w13_absmax=c["w13_absmax"], w2_q=c["w2_q"],
+                          w2_absmax=c["w2_absmax"], E_local=c["E"], H=c["H"], FF=c["FF"]).astype(np.float32)
+    assert np.abs(got - want).max() <= 2 * 2.0 ** -10 * np.abs(want).max()
+    assert (got != want).mean() < 0.1
+
+
+@pytest.mark.parametrize("name", ["fwd_full_T3", "fwd_small_T37"])
+def test_topk_softmax_vs_reference(name, ref):
+    """torch.topk + softmax of the reference on fp16 logits; the oracle sees the same logits through an
+    identity router matrix."""
+    c = ref.golden_forward_case(name)
+    ids_g = np.load(os.path.join(GOLD, name + ".topk_ids.npy"))
+    w_g = np.load(os.path.join(GOLD, name + ".topk_w.npy")).astype(np.float32)
+    E, k = c["E"], c["k"]
+    ids, w, lg = ref.router_topk(c["logits"], np.eye(E, dtype=np.float16), None, k)
+    assert np.array_equal(lg.view(np.uint16), c["logits"].view(np.uint16))
+    untied = np.array([len(np.unique(np.sort(r)[::-1][:k + 1])) == min(k + 1, E) for r in c["logits"].astype(np.float32)])
+    assert untied.any()
+    assert np.array_equal(ids[untied], ids_g[untied])
+    assert np.abs(w.astype(np.float16).astype(np.float32)[untied] - w_g[untied]).max() <= 2.0 ** -10
+
+
+def test_expert_range_filter_and_fp32_combine(ref):
+    H, FF, E, k, T = 128, 64, 4, 2, 6
+    layer = ref.synth_layer(5, E, H, FF)
+    x = ref.normal_f16(6, (T, H))
+    lg = ref.normal_f16(7, (T, E))
+    ids, w, _ = ref.router_topk(lg, np.eye(E, dtype=np.float16), None, k)
+    whole = ref.moe_forward(x, ids, w, **layer, E_local=E, H=H, FF=FF, flags=0).astype(np.float32)
+    parts = np.zeros_like(whole)
+    for r in range(2):
+        sl = slice(2 * r, 2 * r + 2)
+        parts += ref.moe_forward(x, ids, w, w13_q=layer["w13_q"][sl], w13_absmax=layer["w13_absmax"][sl],
+                                 w2_q=layer["w2_q"][sl], w2_absmax=layer["w2_absmax"][sl], E_local=2, e_first=2 * r,
+                                 H=H, FF=FF, flags=0).astype(np.float32)
+    assert np.abs(parts - whole).max() <= 2e-3 * np.abs(whole).max() + 1e-6
+
+
+def test_paged_attention_oracle_vs_dense_numpy(ref):
+    B, Hq, Hkv, D, bs = 2, 16, 2, 64, 16
+    ctx = np.array([37, 5], dtype=np.int32)
+    nblk = 8
+    q = ref.normal_f16(1, (B, Hq, D))
+    kc = ref.normal_f16(2, (nblk, bs, Hkv, D))
+    vc = ref.normal_f16(3, (nblk, bs, Hkv, D))
+    bt = np.array([[5, 2, 7], [1, 0, 0]], dtype=np.int32)
+    out = ref.paged_attn_decode(q, kc, vc, bt, ctx, D ** -0.5).astype(np.float32)
+    for b in range(B):
+        toks = [(bt[b, t // bs], t % bs) for t in range(ctx[b])]
+        for h in range(Hq):
+            K = np.stack([kc[blk, o, h // (Hq // Hkv)] for blk, o in toks]).astype(np.float64)
+            V = np.stack([vc[blk, o, h // (Hq // Hkv)] for blk, o in toks]).astype(np.float64)
+            s = K @ q[b, h].astype(np.float64) * D ** -0.5
+            p = np.exp(s - s.max())
+            o = (p / p.sum()) @ V
+            assert np.abs(out[b, h] - o).max() < 2e-3
