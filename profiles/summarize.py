@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Condense a rocprofv3 run of bench.py (gpurun_out/prof_rNN/) into profiles/rNN_*.  Usage: summarize.py r01"""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+
+tag = sys.argv[1]
+src = f"gpurun_out/prof_{tag}"
+stats = glob.glob(f"{src}/trace/*/*kernel_stats.csv")[0]
+trace = glob.glob(f"{src}/trace/*/*kernel_trace.csv")[0]
+shutil.copy(stats, f"profiles/{tag}_bench_kernel_stats.csv")
+shutil.copy(f"{src}/bench_line.json", f"profiles/{tag}_bench_line.json")
+for extra in glob.glob(f"{src}/trace_bs1/*/*kernel_stats.csv"):
+    shutil.copy(extra, f"profiles/{tag}_bench_bs1_kernel_stats.csv")
+
+groups = collections.defaultdict(list)
+traces = [("bs=32", trace)] + [("bs=1", t) for t in glob.glob(f"{src}/trace_bs1/*/*kernel_trace.csv")]
+for leg, tr_file in traces:
+  for r in csv.DictReader(open(tr_file)):
+      n = r["Kernel_Name"]
+      if "m355" not in n:
+          continue
+      short = n.split("(")[0]
+      for a, b in (("_ZN4m35522moe_gemm_stream_kernelILi0E", "moe_gemm_stream<gate_up,pairs="), ("_ZN4m35522moe_gemm_stream_kernelILi1E", "moe_gemm_stream<down,pairs=")):
+          if short.startswith(a):
+              short = b + short[len(a) + 2] + ">"
+      short = short.replace("_ZN4m35524paged_attn_decode_kernelE", "paged_attn_decode").replace("_ZN4m35518router_topk_kernelE", "router_topk")
+      short = short.replace("_ZN4m35518moe_combine_kernelE", "moe_combine").split("PK")[0].split("EPK")[0]
+      key = (leg, short, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Workgroup_Size_X"]), int(r["LDS_Block_Size"]),
+             int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]))
+      groups[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+
+pmc = collections.defaultdict(list)
+for f in glob.glob(f"{src}/pmc_*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "moe_gemm" in r["Kernel_Name"]:
+            pmc[("gate_up" if "ILi0E" in r["Kernel_Name"] else "down", r["Counter_Name"])].append(float(r["Counter_Value"]))
+
+bench = json.load(open(f"{src}/bench_line.json"))
+with open(f"profiles/{tag}_summary.md", "w") as out:
+    out.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bs1 [--batch-per-gpu 1]`\n\n")
+    out.write("Two runs: the default workload (bs=32 per GPU) and `--batch-per-gpu 1`; both with `--no-bs1` so a row is one configuration.\n\n")
+    out.write("| leg | kernel | workgroups | threads | launches | avg us | min us | max us |\n|---|---|---|---|---|---|---|---|\n")
+    for k, v in sorted(groups.items()):
+        out.write(f"| {k[0]} | {k[1]} | {k[2]} | {k[3]} | {len(v)} | {sum(v) / len(v) / 1e3:.2f} | {min(v) / 1e3:.2f} | {max(v) / 1e3:.2f} |\n")
+    out.write("\n## bench.py line of the same run\n\n```\n" + json.dumps(bench, indent=1) + "\n```\n")
+    if pmc:
+        out.write("\n## HBM traffic of the MoE GEMM kernels (separate --pmc passes over scratch/prof_moe.py, bs=32, per launch)\n\n")
+        out.write("| kernel | counter | launches | mean |\n|---|---|---|---|\n")
+        for k, v in sorted(pmc.items()):
+            out.write(f"| {k[0]} | {k[1]} | {len(v)} | {sum(v) / len(v):.6g} |\n")
+        out.write("\nTCC_EA0_RDREQ counts 128-byte requests here (no 32-byte ones); FETCH_SIZE is in KiB and reads one half of a "
+                  "wide coalesced stream on gfx950, so bytes = 2 x FETCH_SIZE x 1024 = RDREQ x 128.\n")
+print(open(f"profiles/{tag}_summary.md").read()[:3000])

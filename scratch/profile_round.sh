@@ -1,0 +1,13 @@
+#!/bin/bash
+# rocprofv3 kernel-trace summaries of bench.py (bs=32 leg and bs=1 leg separately, so each kernel row is one
+# configuration) + HBM read-request passes on the MoE kernels.  usage: profile_round.sh r01
+tag=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rm -rf gpurun_out/prof_$tag
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag/trace -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bs1 > gpurun_out/prof_${tag}_bench.log 2>&1 || { tail -5 gpurun_out/prof_${tag}_bench.log; exit 1; }
+grep '^{' gpurun_out/prof_${tag}_bench.log > gpurun_out/prof_$tag/bench_line.json
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag/trace_bs1 -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bs1 --batch-per-gpu 1 > gpurun_out/prof_${tag}_bench_bs1.log 2>&1 || { tail -5 gpurun_out/prof_${tag}_bench_bs1.log; exit 1; }
+grep '^{' gpurun_out/prof_${tag}_bench_bs1.log > gpurun_out/prof_$tag/bench_line_bs1.json
+timeout -s KILL 120 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d gpurun_out/prof_$tag/pmc_rd -- python scratch/prof_moe.py 32 2 > gpurun_out/prof_${tag}_pmc.log 2>&1 || { tail -5 gpurun_out/prof_${tag}_pmc.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_$tag/pmc_fetch -- python scratch/prof_moe.py 32 2 > gpurun_out/prof_${tag}_pmc2.log 2>&1 || { tail -5 gpurun_out/prof_${tag}_pmc2.log; exit 1; }
+echo done
