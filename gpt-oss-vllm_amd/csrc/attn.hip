@@ -69,7 +69,8 @@ __global__ __launch_bounds__(ATT_THREADS) void paged_attn_decode_kernel(
     constexpr int ITERS = ATT_PART / 32;
     const int64_t row_stride = (int64_t)Hkv * ATT_D;
 
-    // ---- pass 1: scores ----
+    // ---- pass 1: scores ----  (the V rows are requested together with the K rows: one latency, not two)
+    u32x4_t vv[ITERS];
     {
         u32x4_t kv[ITERS];
 #pragma unroll
@@ -77,7 +78,9 @@ __global__ __launch_bounds__(ATT_THREADS) void paged_attn_decode_kernel(
             const int tl = min(it * 32 + wave * 8 + ts, npt - 1);
             const int t = t0 + tl;
             const int blk = bt[t / block_size];
-            kv[it] = reinterpret_cast<const u32x4_t*>(kc + ((int64_t)blk * block_size + t % block_size) * row_stride + hk * ATT_D)[dc];
+            const int64_t row = ((int64_t)blk * block_size + t % block_size) * row_stride + hk * ATT_D;
+            kv[it] = reinterpret_cast<const u32x4_t*>(kc + row)[dc];
+            vv[it] = reinterpret_cast<const u32x4_t*>(vc + row)[dc];
         }
 #pragma unroll
         for (int it = 0; it < ITERS; it++) {
@@ -129,14 +132,6 @@ __global__ __launch_bounds__(ATT_THREADS) void paged_attn_decode_kernel(
 #pragma unroll
         for (int j = 0; j < 8; j++) o[h][j] = 0.f;
     {
-        u32x4_t vv[ITERS];
-#pragma unroll
-        for (int it = 0; it < ITERS; it++) {
-            const int tl = min(it * 32 + wave * 8 + ts, npt - 1);
-            const int t = t0 + tl;
-            const int blk = bt[t / block_size];
-            vv[it] = reinterpret_cast<const u32x4_t*>(vc + ((int64_t)blk * block_size + t % block_size) * row_stride + hk * ATT_D)[dc];
-        }
 #pragma unroll
         for (int it = 0; it < ITERS; it++) {
             const int tl = it * 32 + wave * 8 + ts;

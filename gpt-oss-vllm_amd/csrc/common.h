@@ -45,10 +45,19 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
 // directly to an indexed vector element (v[j] with an unrolled loop index) was seen to read element 0
 // for every j with hipcc 7.2.
 __device__ __forceinline__ half2_t as_half2(uint32_t v) { return __builtin_bit_cast(half2_t, v); }
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_get(float v) {   // lanes outside ROW_MASK (or reading an invalid lane) get 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+// Wave-wide sum with DPP only (no LDS crossbar round trips); every lane returns the total.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_get<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_get<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_get<0x141>(v);         // row_half_mirror
+    v += dpp_get<0x140>(v);         // row_mirror: every lane now holds its 16-lane row's sum
+    v += dpp_get<0x142, 0xa>(v);    // row_bcast15 into rows 1 and 3
+    v += dpp_get<0x143, 0xc>(v);    // row_bcast31 into rows 2 and 3: lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll

@@ -20,8 +20,6 @@
 // Dequantisation: a byte holds two codes; a 256-entry table of packed half2 (code[lo], code[hi]) is
 // replicated 32x in LDS (entry address = (byte*32 + lane%32)*4) so a wave's lookups never collide on a bank.
 // The code values are fp16-rounded NF4 entries; scales stay fp32.
-#include <cstdlib>
-
 #include "common.h"
 
 namespace m355 {
@@ -97,9 +95,29 @@ __global__ __launch_bounds__(ROUTE_THREADS) void moe_route_kernel(const int32_t*
         if (e >= 0 && e < E_local) atomicAdd(&cnt[e], 1);
     }
     __syncthreads();
-    if (tid == 0) {
-        int run = 0, na = 0, nt = 0;
-        for (int e = 0; e < E_local; e++) {
+    if (tid < 64) {
+        // wave 0: lane l owns experts [l*C, (l+1)*C); exclusive wave scans give where its lists start
+        const int C = (E_local + 63) / 64;
+        const int ea = min(tid * C, E_local), eb = min(ea + C, E_local);
+        int s_cnt = 0, s_act = 0, s_tiles = 0;
+        for (int e = ea; e < eb; e++) {
+            s_cnt += cnt[e];
+            s_act += cnt[e] > 0;
+            s_tiles += (cnt[e] + mt_rows - 1) / mt_rows;
+        }
+        int run = s_cnt, na = s_act, nt = s_tiles;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int a1 = __shfl_up(run, o, 64), a2 = __shfl_up(na, o, 64), a3 = __shfl_up(nt, o, 64);
+            if (tid >= o) { run += a1; na += a2; nt += a3; }
+        }
+        if (tid == 63) {
+            offsets[E_local] = run;
+            *n_active = na;
+            *n_tiles = nt;
+        }
+        run -= s_cnt; na -= s_act; nt -= s_tiles;   // exclusive
+        for (int e = ea; e < eb; e++) {
             offsets[e] = run;
             cur[e] = run;
             if (cnt[e] > 0) active[na++] = e;
@@ -109,9 +127,6 @@ __global__ __launch_bounds__(ROUTE_THREADS) void moe_route_kernel(const int32_t*
             }
             run += cnt[e];
         }
-        offsets[E_local] = run;
-        *n_active = na;
-        *n_tiles = nt;
     }
     __syncthreads();
     for (int p = tid; p < P; p += ROUTE_THREADS) {
@@ -333,11 +348,11 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int THREADS = PAIRS * 256;
     constexpr int RED1 = PAIRS * (MOE_KPARTS - 1) * 64 * 8 * 4;   // one reduction buffer
-    constexpr int NRED = (PAIRS >= 4) ? 1 : 2;                      // 16-wave groups have LDS for one only
+    constexpr int NRED = (PAIRS >= 3) ? 1 : 2;                      // 12/16-wave groups have LDS for one only
 #ifndef M355_FS
 #define M355_FS 1
 #endif
-    constexpr int FS = (PAIRS >= 4) ? 0 : M355_FS;                        // fragment sets - 1 (16 waves rely on occupancy instead)
+    constexpr int FS = (PAIRS >= 3) ? 0 : M355_FS;                        // fragment sets - 1 (16 waves rely on occupancy instead)
     const int NB = K / 64, NP = R / 32;
     const int NPG = (NP + PAIRS - 1) / PAIRS;
     // work item = (token tile of one expert, group of PAIRS row-tile pairs); a workgroup takes a contiguous range
@@ -398,14 +413,24 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     sA = sAn;
     sB = sBn;
 
-    {   // code table: THREADS/256 threads share one byte value
-        const float tab[16] = M355_NF4_TABLE;
-        constexpr int TPB = THREADS / 256;          // threads per byte value (1 or 2)
-        const int bv = tid / TPB, sub = tid % TPB;
-        const half2_t hv = {(half_t)tab[bv & 15], (half_t)tab[bv >> 4]};
-        const uint32_t v = __builtin_bit_cast(uint32_t, hv);
+    // code table: entry (byte, replica) = half2(code[byte & 15], code[byte >> 4]).  The 16 codes come from
+    // immediates (a select chain in 16 threads, parked at the start of the reduction area), not from memory.
+    {
+        half_t* codes = reinterpret_cast<half_t*>(red);
+        if (tid < 16) {
+            const float tab[16] = M355_NF4_TABLE;
+            float c = 0.f;
 #pragma unroll
-        for (int i = 0; i < 32 / TPB; i++) lut[bv * 32 + sub * (32 / TPB) + i] = v;
+            for (int j = 0; j < 16; j++) c = (tid == j) ? tab[j] : c;
+            codes[tid] = (half_t)c;
+        }
+        lds_barrier();
+        for (int i = tid; i < 256 * 32; i += THREADS) {
+            const int bv = i >> 5;
+            const half2_t hv = {codes[bv & 15], codes[bv >> 4]};
+            lut[i] = __builtin_bit_cast(uint32_t, hv);
+        }
+        lds_barrier();   // codes sits in the reduction area: everyone is done reading it before the first item
     }
     const uint32_t* lut_lane = lut + (lane & 31);
 
@@ -585,8 +610,6 @@ static int device_setup(int dev, int* cus) {
         if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2>)) return rc;
         if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 1>)) return rc;
         if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 2>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 4>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 4>)) return rc;
         int v = 0;
         if (int rc = hip_status(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute")) return rc;
         ncu[d] = v > 0 ? v : 256;
@@ -597,7 +620,7 @@ static int device_setup(int dev, int* cus) {
 }
 
 static int stream_lds_bytes(int K, int mt_rows, int pairs) {
-    return LUT_BYTES + (pairs >= 4 ? 1 : 2) * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4 + mt_rows * (K * 2 + XS_PAD);
+    return LUT_BYTES + (pairs >= 3 ? 1 : 2) * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4 + mt_rows * (K * 2 + XS_PAD);
 }
 
 // W [R][K] per expert.  K <= 48 blocks: streaming kernel, one or two workgroups per CU; else the general kernel.
@@ -606,15 +629,10 @@ static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, c
                        int k_top, int mt_rows, int slots, half_t* outp, int cus, hipStream_t st) {
     const int NP = R / 32, NB = K / 64;
     if (NB <= MOE_KPARTS * MOE_CHUNK) {
-        const int max_tiles = slots + ws.max_pairs / mt_rows;   // sum over experts of ceil(M_e / mt_rows) stays below this
+        // upper bound of sum_e ceil(M_e / mt_rows): with T <= 16 a token tile holds a whole expert (M_e <= T = mt_rows)
+        const int max_tiles = (ws.max_pairs / k_top <= MOE_MAX_MT) ? slots : slots + ws.max_pairs / mt_rows;
         const int items2 = max_tiles * ((NP + 1) / 2);
-        if (items2 >= 2 * cus && getenv("M355_PAIRS4")) {
-            const int lds = stream_lds_bytes(K, mt_rows, 4);
-            const int items4 = max_tiles * ((NP + 3) / 4);
-            const int grid = items4 < cus ? items4 : cus;
-            moe_gemm_stream_kernel<MODE, 4><<<dim3(grid), dim3(1024), lds, st>>>(xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0,
-                                                                                 ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp);
-        } else if (items2 >= 2 * cus) {
+        if (2 * items2 >= cus) {   // 8-wave workgroups unless even those would leave most CUs idle
             const int lds = stream_lds_bytes(K, mt_rows, 2);
             const int grid = items2 < cus ? items2 : cus;
             moe_gemm_stream_kernel<MODE, 2><<<dim3(grid), dim3(512), lds, st>>>(xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0,

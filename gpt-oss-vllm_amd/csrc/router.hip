@@ -19,9 +19,36 @@ __device__ __forceinline__ void wave_argmax(float& v, int& idx) {
     }
 }
 
+// E <= 64: lane e holds logit e; its rank is the number of logits that beat it (larger, or equal with a
+// smaller index), found with E scalar broadcasts; ranks < k are the picks, in order.
+__device__ __forceinline__ void topk_softmax_wave64(float mine, int E, int k, int32_t* ids_out, float* w_out) {
+    const int lane = threadIdx.x & 63;
+    const bool valid = lane < E && !(mine != mine);
+    const float v = valid ? mine : -INFINITY;
+    int rank = 0;
+    for (int e = 0; e < E; e++) {
+        const float o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), e));
+        rank += (o > v || (o == v && e < lane)) ? 1 : 0;
+    }
+    if (lane >= E) rank = 64;
+    const unsigned long long top = __ballot(rank == 0);
+    const int l0 = top ? __builtin_ctzll(top) : 0;
+    const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l0));
+    const float p = (rank < k) ? __expf(v - mx) : 0.f;
+    const float sum = wave_sum(p);
+    if (rank < k) {
+        ids_out[rank] = lane;
+        w_out[rank] = p / sum;
+    }
+}
+
 // Selects top-k of logit[0..E) (LDS, fp32 values that are exact fp16 numbers); run by one whole wave.
 __device__ __forceinline__ void topk_softmax_wave(float* logit, int E, int k, int32_t* ids_out, float* w_out) {
     const int lane = threadIdx.x & 63;
+    if (E <= 64) {
+        topk_softmax_wave64(lane < E ? logit[lane] : 0.f, E, k, ids_out, w_out);
+        return;
+    }
     float myv = 0.f;
     int myid = 0;
     for (int j = 0; j < k; j++) {
@@ -60,16 +87,29 @@ __global__ __launch_bounds__(ROUTER_THREADS) void router_topk_kernel(const half_
     const u32x4_t* xr = reinterpret_cast<const u32x4_t*>(x + (int64_t)t * H);
     for (int e0 = wave * 4; e0 < E; e0 += NW * 4) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int c = lane; c < chunks; c += 64) {
-            const u32x4_t xv = xr[c];
+        // six 16-byte pieces of x and of four router rows per lane and round, all requested before any is used
+        constexpr int U = 6;
+        for (int cbase = 0; cbase < chunks; cbase += 64 * U) {
+            u32x4_t xv[U], wv[U][4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int e = (e0 + i < E) ? e0 + i : E - 1;
-                const u32x4_t wv = reinterpret_cast<const u32x4_t*>(wr + (int64_t)e * H)[c];
+            for (int u = 0; u < U; u++) {
+                const int c = min(cbase + u * 64 + lane, chunks - 1);
+                xv[u] = xr[c];
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    acc[i] = __builtin_amdgcn_fdot2(as_half2(xv[j]), as_half2(wv[j]),
-                                                    acc[i], false);
+                for (int i = 0; i < 4; i++) {
+                    const int e = (e0 + i < E) ? e0 + i : E - 1;
+                    wv[u][i] = reinterpret_cast<const u32x4_t*>(wr + (int64_t)e * H)[c];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (cbase + u * 64 + lane < chunks) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            acc[i] = __builtin_amdgcn_fdot2(as_half2(xv[u][j]), as_half2(wv[u][i][j]), acc[i], false);
+                }
             }
         }
 #pragma unroll
