@@ -150,6 +150,12 @@ __device__ __forceinline__ float row_bcast(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x150 + I, 0xf, 0xf, false));
 }
 
+// acc += (lane 16*row + I's value of s, broadcast over the 16-lane row) * p, as one VOP2 DPP instruction.
+template <int I>
+__device__ __forceinline__ void fmac_row_bcast(float& acc, float s, float p) {
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(s), "v"(p), "n"(I));
+}
+
 __device__ __forceinline__ half8_t lut4(const uint32_t* lut_lane, uint32_t d) {
     u32x4_t r;
     r[0] = lut_lane[(d & 0xffu) * 32];
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     constexpr int RED1 = PAIRS * (MOE_KPARTS - 1) * 64 * 8 * 4;   // one reduction buffer
     constexpr int NRED = (PAIRS >= 3) ? 1 : 2;                      // 12/16-wave groups have LDS for one only
 #ifndef M355_FS
-#define M355_FS 1
+#define M355_FS 0
 #endif
     constexpr int FS = (PAIRS >= 3) ? 0 : M355_FS;                        // fragment sets - 1 (16 waves rely on occupancy instead)
     const int NB = K / 64, NP = R / 32;
@@ -363,8 +369,6 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
 
     uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
     unsigned char* red = smem + LUT_BYTES;
-    unsigned char* xs = smem + LUT_BYTES + NRED * RED1;
-    const int XS = K * 2 + XS_PAD;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -446,9 +450,6 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     // lookups, matrix cores and VALU overlap.
 #define M355_FETCH(I)                                                                                       \
     {                                                                                                       \
-        const unsigned char* xb = xrow + min(bq0 + I, blast) * 128;                                       \
-        fb[I & FS][0] = *reinterpret_cast<const half8_t*>(xb);                                               \
-        fb[I & FS][1] = *reinterpret_cast<const half8_t*>(xb + 16);                                          \
         fa[I & FS][0] = lut4(lut_lane, W[I][0]);                                                             \
         fa[I & FS][2] = lut4(lut_lane, W[I][2]);                                                             \
         fa[I & FS][1] = lut4(lut_lane, W[I][1]);                                                             \
@@ -460,10 +461,10 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
 #define M355_MFMA(I)                                                                                        \
     {                                                                                                       \
         const float4_t z = {0.f, 0.f, 0.f, 0.f};                                                            \
-        pa[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][0], fb[I & FS][0], z, 0, 0, 0);         \
-        pb[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][2], fb[I & FS][0], z, 0, 0, 0);         \
-        pa[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][1], fb[I & FS][1], pa[I & FS], 0, 0, 0); \
-        pb[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][3], fb[I & FS][1], pb[I & FS], 0, 0, 0); \
+        pa[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][0], xb[I][0], z, 0, 0, 0);         \
+        pb[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][2], xb[I][0], z, 0, 0, 0);         \
+        pa[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][1], xb[I][1], pa[I & FS], 0, 0, 0); \
+        pb[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][3], xb[I][1], pb[I & FS], 0, 0, 0); \
     }                                                                                                       \
     M355_SB
 
@@ -482,11 +483,22 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
 #define M355_MFMA(I)
 #define M355_SCALE(I) accA[0] += sA[0]; accB[0] += sB[0];
 #endif
+#if defined(M355_EXP) && M355_EXP == 1   /* no table lookups: fragments are the raw packed words */
+#undef M355_FETCH
+#define M355_FETCH(I) { _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) { u32x4_t r_ = {W[I][j_], W[I][j_] >> 3, W[I][j_] >> 5, W[I][j_] >> 7}; fa[I & FS][j_] = __builtin_bit_cast(half8_t, r_ & 0x03ff03ffu); } M355_LOAD(I) }
+#elif defined(M355_EXP) && M355_EXP == 2   /* no MFMAs */
+#undef M355_MFMA
+#define M355_MFMA(I) { _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) asm volatile("" ::"v"(fa[I & FS][j_])); pa[I & FS] = __builtin_bit_cast(float4_t, xb[I][0]); pb[I & FS] = __builtin_bit_cast(float4_t, xb[I][1]); }
+#elif defined(M355_EXP) && M355_EXP == 3   /* no absmax scaling */
+#undef M355_SCALE
+#define M355_SCALE(I) accA += pa[I & FS]; accB += pb[I & FS];
+#endif
 #define M355_STEP(I) M355_FETCH(I + 1) M355_MFMA(I) M355_SCALE(I - 1)
 #define M355_PLAIN(I) M355_FETCH(I) M355_MFMA(I) M355_SCALE(I)
 
     int staged_tile = -1;
     int round = 0;
+    half8_t xb[MOE_CHUNK][2];
     for (int it = it0; it < it1; it++) {
         const int tt = it / NPG, pg = it - tt * NPG;
         const int e = tile_expert[tt];
@@ -496,22 +508,23 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
         const int p = pg * PAIRS + pl;
         const bool live = p < NP;
         if (tt != staged_tile) {
-            // every wave is past the previous reduction barrier, so nobody still reads xs
-            const int cpr = K / 8;
-            for (int row = 0; row < mt; row++) {
-                const int pos = pos0 + row;
-                const int64_t src_row = (MODE == 0) ? (int64_t)(sorted[pos] / k_top) : (int64_t)pos;
-                const u32x4_t* src = reinterpret_cast<const u32x4_t*>(xin + src_row * K);
-                for (int c = tid; c < cpr; c += THREADS) *reinterpret_cast<u32x4_t*>(xs + row * XS + c * 16) = src[c];
+            // this lane's B fragments of the whole K-part: token row n (clamped), columns 64b + 16g .. + 15 of each
+            // block, straight from global memory into registers, where they stay until the token tile changes
+            const int pos = pos0 + min(n, mt - 1);
+            const int64_t src_row = (MODE == 0) ? (int64_t)(sorted[pos] / k_top) : (int64_t)pos;
+            const u32x4_t* src = reinterpret_cast<const u32x4_t*>(xin + src_row * K) + 2 * g;
+#pragma unroll
+            for (int i = 0; i < MOE_CHUNK; i++) {
+                const int bb = min(bq0 + i, blast);
+                xb[i][0] = __builtin_bit_cast(half8_t, src[8 * bb]);
+                xb[i][1] = __builtin_bit_cast(half8_t, src[8 * bb + 1]);
             }
             staged_tile = tt;
-            lds_barrier();
         }
         M355_POINT_AT(it + 1, it + 1 < it1)
 
         float4_t accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
-        const unsigned char* xrow = xs + min(n, mt - 1) * XS + g * 32;
-        half8_t fa[FS + 1][4], fb[FS + 1][2];
+        half8_t fa[FS + 1][4];
         float4_t pa[FS + 1], pb[FS + 1];
         if (FS) {
             M355_FETCH(0) M355_FETCH(1) M355_MFMA(0)
@@ -533,7 +546,9 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
             dst[0] = accA;
             dst[1] = accB;
         }
+#if !(defined(M355_EXP) && M355_EXP == 4)   /* experiment 4: no cross-wave reduction barrier */
         lds_barrier();
+#endif
         if (q == 0 && live) {
 #pragma unroll
             for (int qq = 0; qq < MOE_KPARTS - 1; qq++) {
@@ -620,7 +635,8 @@ static int device_setup(int dev, int* cus) {
 }
 
 static int stream_lds_bytes(int K, int mt_rows, int pairs) {
-    return LUT_BYTES + (pairs >= 3 ? 1 : 2) * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4 + mt_rows * (K * 2 + XS_PAD);
+    (void)K; (void)mt_rows;   // activations live in registers
+    return LUT_BYTES + (pairs >= 3 ? 1 : 2) * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4;
 }
 
 // W [R][K] per expert.  K <= 48 blocks: streaming kernel, one or two workgroups per CU; else the general kernel.
