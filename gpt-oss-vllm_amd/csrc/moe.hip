@@ -146,14 +146,44 @@ __global__ __launch_bounds__(ROUTE_THREADS) void moe_route_kernel(const int32_t*
 // Broadcast lane (16*row + I)'s value to the 16 lanes of its row.
 template <int I>
 __device__ __forceinline__ float row_bcast(float v) {
-    const int iv = __builtin_bit_cast(int, v);   // old = source: every lane is written, no zero-init needed
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x150 + I, 0xf, 0xf, false));
+    const int iv = __builtin_bit_cast(int, v);   // every lane is written; the zero "old" value folds away
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, iv, 0x150 + I, 0xf, 0xf, true));
 }
 
 // acc += (lane 16*row + I's value of s, broadcast over the 16-lane row) * p, as one VOP2 DPP instruction.
 template <int I>
 __device__ __forceinline__ void fmac_row_bcast(float& acc, float s, float p) {
     asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(s), "v"(p), "n"(I));
+}
+
+// acc += (lane 16*row + I's value of s) * p like fmac_row_bcast, for use AFTER `ready` has been computed by an
+// instruction the compiler knows: the compiler places the wait states an MFMA result needs before a vector
+// instruction reads it only for its own instructions, never for inline assembly, so p (an MFMA result) is safe to
+// read here only because `ready` was derived from the same MFMA's result and this statement depends on it.
+template <int I>
+__device__ __forceinline__ float fmac_row_bcast_after(float acc, float s, float p, float ready) {
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(s), "v"(p), "n"(I), "v"(ready));
+    return acc;
+}
+
+// Four table lookups with one v_perm_b32 each for the address: byte k of d lands in bits 8..15 above the lane's
+// replica offset (low byte of lbase), so the table has 256 bytes per byte value (LUTP_BYTES in all) and must start
+// at an LDS address that is a multiple of 64 KiB; bits 16..31 of lbase carry that start.  The kernels that use it
+// declare no static LDS, so their dynamic LDS (and the table) starts at 0.
+constexpr int LUTP_BYTES = 256 * 256;
+typedef const uint32_t __attribute__((address_space(3))) lds_u32_t;
+__device__ __forceinline__ uint32_t lds_load_u32(uint32_t addr) { return *reinterpret_cast<lds_u32_t*>(addr); }
+__device__ __forceinline__ uint32_t lutp_lane_base(const unsigned char* lut_bytes, int lane) {
+    typedef const unsigned char __attribute__((address_space(3))) lds_u8_t;
+    return (uint32_t)(size_t)(lds_u8_t*)lut_bytes + (lane & 31) * 4;
+}
+__device__ __forceinline__ half8_t lut4p(uint32_t lbase, uint32_t d) {
+    u32x4_t r;
+    r[0] = lds_load_u32(__builtin_amdgcn_perm(d, lbase, 0x03020400u));
+    r[1] = lds_load_u32(__builtin_amdgcn_perm(d, lbase, 0x03020500u));
+    r[2] = lds_load_u32(__builtin_amdgcn_perm(d, lbase, 0x03020600u));
+    r[3] = lds_load_u32(__builtin_amdgcn_perm(d, lbase, 0x03020700u));
+    return __builtin_bit_cast(half8_t, r);
 }
 
 __device__ __forceinline__ half8_t lut4(const uint32_t* lut_lane, uint32_t d) {
@@ -368,7 +398,7 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     if (it0 >= it1) return;
 
     uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
-    unsigned char* red = smem + LUT_BYTES;
+    unsigned char* red = smem + LUTP_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -429,14 +459,14 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
             codes[tid] = (half_t)c;
         }
         lds_barrier();
-        for (int i = tid; i < 256 * 32; i += THREADS) {
+        for (int i = tid; i < 256 * 32; i += THREADS) {   // 32 replicas (one per bank) in each 256-byte row
             const int bv = i >> 5;
             const half2_t hv = {codes[bv & 15], codes[bv >> 4]};
-            lut[i] = __builtin_bit_cast(uint32_t, hv);
+            lut[bv * 64 + (i & 31)] = __builtin_bit_cast(uint32_t, hv);
         }
         lds_barrier();   // codes sits in the reduction area: everyone is done reading it before the first item
     }
-    const uint32_t* lut_lane = lut + (lane & 31);
+    const uint32_t lbase = lutp_lane_base(smem, lane);
 
     #ifdef M355_WITH_SB   /* pinning the stage order costs ~25 %: the compiler's own interleave is better */
 #define M355_SB __builtin_amdgcn_sched_barrier(0);
@@ -450,10 +480,10 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     // lookups, matrix cores and VALU overlap.
 #define M355_FETCH(I)                                                                                       \
     {                                                                                                       \
-        fa[I & FS][0] = lut4(lut_lane, W[I][0]);                                                             \
-        fa[I & FS][2] = lut4(lut_lane, W[I][2]);                                                             \
-        fa[I & FS][1] = lut4(lut_lane, W[I][1]);                                                             \
-        fa[I & FS][3] = lut4(lut_lane, W[I][3]);                                                             \
+        fa[I & FS][0] = lut4p(lbase, W[I][0]);                                                         \
+        fa[I & FS][2] = lut4p(lbase, W[I][2]);                                                         \
+        fa[I & FS][1] = lut4p(lbase, W[I][1]);                                                         \
+        fa[I & FS][3] = lut4p(lbase, W[I][3]);                                                         \
         M355_LOAD(I)                                                                                        \
     }                                                                                                       \
     M355_SB
@@ -468,12 +498,23 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     }                                                                                                       \
     M355_SB
 
+#ifdef M355_PLAIN_SCALE
 #define M355_SCALE(I)                                                                                       \
     _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                         \
         accA[r] += row_bcast<I>(sA[r]) * pa[I & FS][r];                                                      \
         accB[r] += row_bcast<I>(sB[r]) * pb[I & FS][r];                                                      \
     }                                                                                                       \
     M355_SB
+#else
+#define M355_SCALE(I)                                                                                       \
+    accA[0] += row_bcast<I>(sA[0]) * pa[I & FS][0];                                                          \
+    accB[0] += row_bcast<I>(sB[0]) * pb[I & FS][0];                                                          \
+    _Pragma("unroll") for (int r = 1; r < 4; r++) {                                                         \
+        accA[r] = fmac_row_bcast_after<I>(accA[r], sA[r], pa[I & FS][r], accA[0]);                           \
+        accB[r] = fmac_row_bcast_after<I>(accB[r], sB[r], pb[I & FS][r], accB[0]);                           \
+    }                                                                                                       \
+    M355_SB
+#endif
 
 #ifdef M355_EXP_NOCOMPUTE   /* experiment: keep the loads, drop table lookups and MFMAs */
 #undef M355_FETCH
@@ -636,7 +677,7 @@ static int device_setup(int dev, int* cus) {
 
 static int stream_lds_bytes(int K, int mt_rows, int pairs) {
     (void)K; (void)mt_rows;   // activations live in registers
-    return LUT_BYTES + (pairs >= 3 ? 1 : 2) * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4;
+    return LUTP_BYTES + (pairs >= 3 ? 1 : 2) * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4;
 }
 
 // W [R][K] per expert.  K <= 48 blocks: streaming kernel, one or two workgroups per CU; else the general kernel.
