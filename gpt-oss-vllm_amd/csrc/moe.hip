@@ -384,11 +384,6 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int THREADS = PAIRS * 256;
     constexpr int RED1 = PAIRS * (MOE_KPARTS - 1) * 64 * 8 * 4;   // one reduction buffer
-    constexpr int NRED = (PAIRS >= 3) ? 1 : 2;                      // 12/16-wave groups have LDS for one only
-#ifndef M355_FS
-#define M355_FS 0
-#endif
-    constexpr int FS = (PAIRS >= 3) ? 0 : M355_FS;                        // fragment sets - 1 (16 waves rely on occupancy instead)
     const int NB = K / 64, NP = R / 32;
     const int NPG = (NP + PAIRS - 1) / PAIRS;
     // work item = (token tile of one expert, group of PAIRS row-tile pairs); a workgroup takes a contiguous range
@@ -411,39 +406,41 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
 
     // Register ring: W[i] holds block i of the current item until its table lookups are issued, then takes the
     // same block of the NEXT item straight away, so one item's worth of HBM reads (12 KiB per wave) is always in
-    // flight behind the compute.  Past the end of the range the loads re-read one resident line (step 0).
+    // flight behind the compute.  A load is one instruction: wave-uniform base (SGPR pair, set once per item) plus a
+    // per-lane byte offset that never changes (voff[i]: lane * 16 + 1 KiB per block; slots past the end of the
+    // wave's K-part re-read its last block and carry a zero scale).
     u32x4_t W[MOE_CHUNK];
     float4_t sA, sB, sAn, sBn;
-    const u32x4_t* wt_next;
-    int step_next;
+    const unsigned char* wbase_next;
+    uint32_t voff[MOE_CHUNK];
+#pragma unroll
+    for (int i = 0; i < MOE_CHUNK; i++) voff[i] = (uint32_t)lane * 16u + (uint32_t)(min(bq0 + i, blast) - bq0) * 1024u;
 
-#define M355_POINT_AT(IT, VALID)                                                                              \
+    // aim the ring loads at item IT and request its absmax: lane (n, g) gets rows 4g..4g+3 of both tiles at block bq0 + n
+#define M355_POINT_AT(IT)                                                                                     \
     {                                                                                                         \
-        const int itc_ = (VALID) ? (IT) : it0;                                                                \
-        const int tt_ = itc_ / NPG, pg_ = itc_ - tt_ * NPG;                                                   \
+        const int tt_ = (IT) / NPG, pg_ = (IT) - tt_ * NPG;                                                   \
         const int e_ = tile_expert[tt_];                                                                      \
         const int pc_ = min(pg_ * PAIRS + pl, NP - 1);                                                        \
-        wt_next = reinterpret_cast<const u32x4_t*>(wq + (size_t)e_ * wq_expert) + (size_t)pc_ * NB * 64 + lane; \
-        step_next = (VALID) ? 64 : 0;                                                                         \
+        wbase_next = wq + (size_t)e_ * wq_expert + ((size_t)pc_ * NB + bq0) * 1024;                           \
         const float4_t* am_ = reinterpret_cast<const float4_t*>(wam + (size_t)e_ * am_expert);                \
         const int bs_ = min(bq0 + n, blast);                                                                  \
         const float keep_ = (bq0 + n < bq1) ? 1.f : 0.f; /* blocks past the K-part count for nothing */       \
         sAn = am_[((size_t)(pc_ * 2 + 0) * 4 + g) * NB + bs_] * keep_;                                        \
         sBn = am_[((size_t)(pc_ * 2 + 1) * 4 + g) * NB + bs_] * keep_;                                        \
     }
-#ifdef M355_EXP_NOLOAD   /* experiment: compute on whatever the first loads brought */
-#define M355_LOAD(I) if (it < 0) W[I] = __builtin_nontemporal_load(wt_next + (size_t)min(bq0 + I, blast) * step_next);
-#else
-#define M355_LOAD(I) W[I] = __builtin_nontemporal_load(wt_next + (size_t)min(bq0 + I, blast) * step_next);
-#endif
-
-    M355_POINT_AT(it0, true)
-    {
-        const int it = -1;   // (only read by the no-load experiment build)
-        (void)it;
-#pragma unroll
-        for (int i = 0; i < MOE_CHUNK; i++) M355_LOAD(i)
+    // (the empty asm keeps the offset a 32-bit register at the point of use, which is what lets the compiler pick
+    // the SGPR-base + VGPR-offset addressing form instead of widening the offsets to 64 bits outside the loop)
+#define M355_LOAD(I)                                                                                          \
+    {                                                                                                         \
+        asm("" : "+v"(voff[I]));                                                                              \
+        W[I] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wbase_next + voff[I]));            \
     }
+#define M355_NO_LOAD(I)
+
+    M355_POINT_AT(it0)
+#pragma unroll
+    for (int i = 0; i < MOE_CHUNK; i++) M355_LOAD(i)
     sA = sAn;
     sB = sBn;
 
@@ -468,144 +465,109 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     }
     const uint32_t lbase = lutp_lane_base(smem, lane);
 
-    #ifdef M355_WITH_SB   /* pinning the stage order costs ~25 %: the compiler's own interleave is better */
-#define M355_SB __builtin_amdgcn_sched_barrier(0);
-#else
-#define M355_SB
-#endif
-    // Every wave runs MOE_CHUNK blocks per item without branches: blocks past the end of its K-part re-read the
-    // part's last block and carry a zero scale.  Per block: M355_FETCH (16 table lookups = four A fragments, two B
-    // fragments, into fragment set I&1, then the ring load of the next item's block I), M355_MFMA (four MFMAs into
-    // partial set I&1), M355_SCALE (absmax FMAs).  The body runs FETCH(I+1), MFMA(I), SCALE(I-1) in that order so
-    // lookups, matrix cores and VALU overlap.
-#define M355_FETCH(I)                                                                                       \
+    // Every wave runs MOE_CHUNK blocks per item without branches.  Per block: M355_FETCH (16 table lookups = four A
+    // fragments, then the ring load that refills the block's registers), M355_MFMA (four MFMAs against the
+    // register-resident B fragments), M355_SCALE (absmax FMAs on the 16x16 partial products).  The compiler
+    // interleaves neighbouring blocks.
+#define M355_FETCH(I, LOAD)                                                                                 \
     {                                                                                                       \
-        fa[I & FS][0] = lut4p(lbase, W[I][0]);                                                         \
-        fa[I & FS][2] = lut4p(lbase, W[I][2]);                                                         \
-        fa[I & FS][1] = lut4p(lbase, W[I][1]);                                                         \
-        fa[I & FS][3] = lut4p(lbase, W[I][3]);                                                         \
-        M355_LOAD(I)                                                                                        \
-    }                                                                                                       \
-    M355_SB
-
+        fa[0] = lut4p(lbase, W[I][0]);                                                                      \
+        fa[2] = lut4p(lbase, W[I][2]);                                                                      \
+        fa[1] = lut4p(lbase, W[I][1]);                                                                      \
+        fa[3] = lut4p(lbase, W[I][3]);                                                                      \
+        LOAD(I)                                                                                             \
+    }
 #define M355_MFMA(I)                                                                                        \
     {                                                                                                       \
         const float4_t z = {0.f, 0.f, 0.f, 0.f};                                                            \
-        pa[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][0], xb[I][0], z, 0, 0, 0);         \
-        pb[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][2], xb[I][0], z, 0, 0, 0);         \
-        pa[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][1], xb[I][1], pa[I & FS], 0, 0, 0); \
-        pb[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][3], xb[I][1], pb[I & FS], 0, 0, 0); \
-    }                                                                                                       \
-    M355_SB
-
-#ifdef M355_PLAIN_SCALE
+        pa = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], xb[I][0], z, 0, 0, 0);                           \
+        pb = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[2], xb[I][0], z, 0, 0, 0);                           \
+        pa = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], xb[I][1], pa, 0, 0, 0);                          \
+        pb = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[3], xb[I][1], pb, 0, 0, 0);                          \
+    }
+    // element 0 of each tile goes through instructions the compiler knows (so it places the MFMA-result wait
+    // states); the other elements follow as single v_fmac_f32_dpp instructions that depend on element 0's result
 #define M355_SCALE(I)                                                                                       \
-    _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                         \
-        accA[r] += row_bcast<I>(sA[r]) * pa[I & FS][r];                                                      \
-        accB[r] += row_bcast<I>(sB[r]) * pb[I & FS][r];                                                      \
-    }                                                                                                       \
-    M355_SB
-#else
-#define M355_SCALE(I)                                                                                       \
-    accA[0] += row_bcast<I>(sA[0]) * pa[I & FS][0];                                                          \
-    accB[0] += row_bcast<I>(sB[0]) * pb[I & FS][0];                                                          \
+    accA[0] += row_bcast<I>(sA[0]) * pa[0];                                                                  \
+    accB[0] += row_bcast<I>(sB[0]) * pb[0];                                                                  \
     _Pragma("unroll") for (int r = 1; r < 4; r++) {                                                         \
-        accA[r] = fmac_row_bcast_after<I>(accA[r], sA[r], pa[I & FS][r], accA[0]);                           \
-        accB[r] = fmac_row_bcast_after<I>(accB[r], sB[r], pb[I & FS][r], accB[0]);                           \
-    }                                                                                                       \
-    M355_SB
-#endif
-
+        accA[r] = fmac_row_bcast_after<I>(accA[r], sA[r], pa[r], accA[0]);                                   \
+        accB[r] = fmac_row_bcast_after<I>(accB[r], sB[r], pb[r], accB[0]);                                   \
+    }
 #ifdef M355_EXP_NOCOMPUTE   /* experiment: keep the loads, drop table lookups and MFMAs */
 #undef M355_FETCH
 #undef M355_MFMA
 #undef M355_SCALE
-#define M355_FETCH(I) asm volatile("" ::"v"(W[I])); M355_LOAD(I)
+#define M355_FETCH(I, LOAD) asm volatile("" ::"v"(W[I])); LOAD(I)
 #define M355_MFMA(I)
 #define M355_SCALE(I) accA[0] += sA[0]; accB[0] += sB[0];
 #endif
-#if defined(M355_EXP) && M355_EXP == 1   /* no table lookups: fragments are the raw packed words */
-#undef M355_FETCH
-#define M355_FETCH(I) { _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) { u32x4_t r_ = {W[I][j_], W[I][j_] >> 3, W[I][j_] >> 5, W[I][j_] >> 7}; fa[I & FS][j_] = __builtin_bit_cast(half8_t, r_ & 0x03ff03ffu); } M355_LOAD(I) }
-#elif defined(M355_EXP) && M355_EXP == 2   /* no MFMAs */
-#undef M355_MFMA
-#define M355_MFMA(I) { _Pragma("unroll") for (int j_ = 0; j_ < 4; j_++) asm volatile("" ::"v"(fa[I & FS][j_])); pa[I & FS] = __builtin_bit_cast(float4_t, xb[I][0]); pb[I & FS] = __builtin_bit_cast(float4_t, xb[I][1]); }
-#elif defined(M355_EXP) && M355_EXP == 3   /* no absmax scaling */
-#undef M355_SCALE
-#define M355_SCALE(I) accA += pa[I & FS]; accB += pb[I & FS];
-#endif
-#define M355_STEP(I) M355_FETCH(I + 1) M355_MFMA(I) M355_SCALE(I - 1)
-#define M355_PLAIN(I) M355_FETCH(I) M355_MFMA(I) M355_SCALE(I)
+#define M355_BLOCK(I, LOAD) M355_FETCH(I, LOAD) M355_MFMA(I) M355_SCALE(I)
+
+    // One work item.  LOAD is M355_LOAD while another item follows in this workgroup's range (the ring then refills
+    // with it) and M355_NO_LOAD for the last one.
+#define M355_ITEM(IT, LOAD, MORE)                                                                           \
+    {                                                                                                       \
+        const int it = (IT);                                                                                \
+        const int tt = it / NPG, pg = it - tt * NPG;                                                        \
+        const int e = tile_expert[tt];                                                                      \
+        const int m0 = tile_m0[tt];                                                                         \
+        const int pos0 = offsets[e] + m0;                                                                   \
+        const int mt = min(mt_rows, offsets[e + 1] - pos0);                                                 \
+        const int p = pg * PAIRS + pl;                                                                      \
+        const bool live = p < NP;                                                                           \
+        if (tt != staged_tile) {                                                                            \
+            /* this lane's B fragments of the whole K-part: token row n (clamped), columns 64b + 16g .. + 15 */ \
+            /* of each block, from global memory into registers, where they stay until the token tile changes */ \
+            const int pos = pos0 + min(n, mt - 1);                                                          \
+            const int64_t src_row = (MODE == 0) ? (int64_t)(sorted[pos] / k_top) : (int64_t)pos;            \
+            const u32x4_t* src = reinterpret_cast<const u32x4_t*>(xin + src_row * K) + 2 * g;               \
+            _Pragma("unroll") for (int i = 0; i < MOE_CHUNK; i++) {                                         \
+                const int bb = min(bq0 + i, blast);                                                         \
+                xb[i][0] = __builtin_bit_cast(half8_t, src[8 * bb]);                                        \
+                xb[i][1] = __builtin_bit_cast(half8_t, src[8 * bb + 1]);                                    \
+            }                                                                                               \
+            staged_tile = tt;                                                                               \
+        }                                                                                                   \
+        if (MORE) M355_POINT_AT(it + 1)                                                                     \
+        float4_t accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};                                  \
+        half8_t fa[4];                                                                                      \
+        float4_t pa, pb;                                                                                    \
+        M355_BLOCK(0, LOAD) M355_BLOCK(1, LOAD) M355_BLOCK(2, LOAD) M355_BLOCK(3, LOAD) M355_BLOCK(4, LOAD) \
+        M355_BLOCK(5, LOAD) M355_BLOCK(6, LOAD) M355_BLOCK(7, LOAD) M355_BLOCK(8, LOAD) M355_BLOCK(9, LOAD) \
+        M355_BLOCK(10, LOAD) M355_BLOCK(11, LOAD)                                                           \
+        sA = sAn;                                                                                           \
+        sB = sBn;                                                                                           \
+        /* sum the K-parts through LDS (two buffers in turn, so one barrier per item is enough) */          \
+        float4_t* rbuf = reinterpret_cast<float4_t*>(red + (round & 1) * RED1);                             \
+        round++;                                                                                            \
+        if (q > 0) {                                                                                        \
+            float4_t* dst = rbuf + ((size_t)(pl * (MOE_KPARTS - 1) + (q - 1)) * 64 + lane) * 2;             \
+            dst[0] = accA;                                                                                  \
+            dst[1] = accB;                                                                                  \
+        }                                                                                                   \
+        lds_barrier();                                                                                      \
+        if (q == 0 && live) {                                                                               \
+            _Pragma("unroll") for (int qq = 0; qq < MOE_KPARTS - 1; qq++) {                                 \
+                const float4_t* src = rbuf + ((size_t)(pl * (MOE_KPARTS - 1) + qq) * 64 + lane) * 2;        \
+                accA += src[0];                                                                             \
+                accB += src[1];                                                                             \
+            }                                                                                               \
+            if (n < mt) gemm_epilogue<MODE>(accA, accB, outp, pos0 + n, R, NP, p, g);                       \
+        }                                                                                                   \
+    }
 
     int staged_tile = -1;
     int round = 0;
     half8_t xb[MOE_CHUNK][2];
-    for (int it = it0; it < it1; it++) {
-        const int tt = it / NPG, pg = it - tt * NPG;
-        const int e = tile_expert[tt];
-        const int m0 = tile_m0[tt];
-        const int pos0 = offsets[e] + m0;
-        const int mt = min(mt_rows, offsets[e + 1] - pos0);
-        const int p = pg * PAIRS + pl;
-        const bool live = p < NP;
-        if (tt != staged_tile) {
-            // this lane's B fragments of the whole K-part: token row n (clamped), columns 64b + 16g .. + 15 of each
-            // block, straight from global memory into registers, where they stay until the token tile changes
-            const int pos = pos0 + min(n, mt - 1);
-            const int64_t src_row = (MODE == 0) ? (int64_t)(sorted[pos] / k_top) : (int64_t)pos;
-            const u32x4_t* src = reinterpret_cast<const u32x4_t*>(xin + src_row * K) + 2 * g;
-#pragma unroll
-            for (int i = 0; i < MOE_CHUNK; i++) {
-                const int bb = min(bq0 + i, blast);
-                xb[i][0] = __builtin_bit_cast(half8_t, src[8 * bb]);
-                xb[i][1] = __builtin_bit_cast(half8_t, src[8 * bb + 1]);
-            }
-            staged_tile = tt;
-        }
-        M355_POINT_AT(it + 1, it + 1 < it1)
-
-        float4_t accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
-        half8_t fa[FS + 1][4];
-        float4_t pa[FS + 1], pb[FS + 1];
-        if (FS) {
-            M355_FETCH(0) M355_FETCH(1) M355_MFMA(0)
-            M355_STEP(1) M355_STEP(2) M355_STEP(3) M355_STEP(4) M355_STEP(5)
-            M355_STEP(6) M355_STEP(7) M355_STEP(8) M355_STEP(9) M355_STEP(10)
-            M355_MFMA(11) M355_SCALE(10) M355_SCALE(11)
-        } else {
-            M355_PLAIN(0) M355_PLAIN(1) M355_PLAIN(2) M355_PLAIN(3) M355_PLAIN(4) M355_PLAIN(5)
-            M355_PLAIN(6) M355_PLAIN(7) M355_PLAIN(8) M355_PLAIN(9) M355_PLAIN(10) M355_PLAIN(11)
-        }
-        sA = sAn;
-        sB = sBn;
-
-        // sum the K-parts through LDS (two buffers in turn, so one barrier per item is enough)
-        float4_t* rbuf = reinterpret_cast<float4_t*>(red + (round & (NRED - 1)) * RED1);
-        round++;
-        if (q > 0) {
-            float4_t* dst = rbuf + ((size_t)(pl * (MOE_KPARTS - 1) + (q - 1)) * 64 + lane) * 2;
-            dst[0] = accA;
-            dst[1] = accB;
-        }
-#if !(defined(M355_EXP) && M355_EXP == 4)   /* experiment 4: no cross-wave reduction barrier */
-        lds_barrier();
-#endif
-        if (q == 0 && live) {
-#pragma unroll
-            for (int qq = 0; qq < MOE_KPARTS - 1; qq++) {
-                const float4_t* src = rbuf + ((size_t)(pl * (MOE_KPARTS - 1) + qq) * 64 + lane) * 2;
-                accA += src[0];
-                accB += src[1];
-            }
-            if (n < mt) gemm_epilogue<MODE>(accA, accB, outp, pos0 + n, R, NP, p, g);
-        }
-        if (NRED == 1) lds_barrier();   // the single reduction buffer is rewritten by the next item
-    }
-#undef M355_PLAIN
-#undef M355_STEP
+    for (int itx = it0; itx < it1 - 1; itx++) M355_ITEM(itx, M355_LOAD, true)
+    M355_ITEM(it1 - 1, M355_NO_LOAD, false)
+#undef M355_ITEM
+#undef M355_BLOCK
 #undef M355_SCALE
 #undef M355_MFMA
 #undef M355_FETCH
+#undef M355_NO_LOAD
 #undef M355_LOAD
 #undef M355_POINT_AT
 }
@@ -677,7 +639,7 @@ static int device_setup(int dev, int* cus) {
 
 static int stream_lds_bytes(int K, int mt_rows, int pairs) {
     (void)K; (void)mt_rows;   // activations live in registers
-    return LUTP_BYTES + (pairs >= 3 ? 1 : 2) * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4;
+    return LUTP_BYTES + 2 * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4;
 }
 
 // W [R][K] per expert.  K <= 48 blocks: streaming kernel, one or two workgroups per CU; else the general kernel.
