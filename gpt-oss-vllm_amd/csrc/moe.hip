@@ -178,11 +178,16 @@ __device__ __forceinline__ uint32_t lutp_lane_base(const unsigned char* lut_byte
     return (uint32_t)(size_t)(lds_u8_t*)lut_bytes + (lane & 31) * 4;
 }
 __device__ __forceinline__ half8_t lut4p(uint32_t lbase, uint32_t d) {
+    // the four addresses are formed first, in four registers, and the four reads follow: alternating one address
+    // with one read through a single temporary register makes every instruction wait for the one before it
+    uint32_t a0 = __builtin_amdgcn_perm(d, lbase, 0x03020400u), a1 = __builtin_amdgcn_perm(d, lbase, 0x03020500u);
+    uint32_t a2 = __builtin_amdgcn_perm(d, lbase, 0x03020600u), a3 = __builtin_amdgcn_perm(d, lbase, 0x03020700u);
+    asm("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
     u32x4_t r;
-    r[0] = lds_load_u32(__builtin_amdgcn_perm(d, lbase, 0x03020400u));
-    r[1] = lds_load_u32(__builtin_amdgcn_perm(d, lbase, 0x03020500u));
-    r[2] = lds_load_u32(__builtin_amdgcn_perm(d, lbase, 0x03020600u));
-    r[3] = lds_load_u32(__builtin_amdgcn_perm(d, lbase, 0x03020700u));
+    r[0] = lds_load_u32(a0);
+    r[1] = lds_load_u32(a1);
+    r[2] = lds_load_u32(a2);
+    r[3] = lds_load_u32(a3);
     return __builtin_bit_cast(half8_t, r);
 }
 
@@ -384,6 +389,10 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int THREADS = PAIRS * 256;
     constexpr int RED1 = PAIRS * (MOE_KPARTS - 1) * 64 * 8 * 4;   // one reduction buffer
+#ifndef M355_FS
+#define M355_FS 0
+#endif
+    constexpr int FS = M355_FS;   // 1: two fragment sets, pipelined steps
     const int NB = K / 64, NP = R / 32;
     const int NPG = (NP + PAIRS - 1) / PAIRS;
     // work item = (token tile of one expert, group of PAIRS row-tile pairs); a workgroup takes a contiguous range
@@ -471,28 +480,28 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     // interleaves neighbouring blocks.
 #define M355_FETCH(I, LOAD)                                                                                 \
     {                                                                                                       \
-        fa[0] = lut4p(lbase, W[I][0]);                                                                      \
-        fa[2] = lut4p(lbase, W[I][2]);                                                                      \
-        fa[1] = lut4p(lbase, W[I][1]);                                                                      \
-        fa[3] = lut4p(lbase, W[I][3]);                                                                      \
+        fa[I & FS][0] = lut4p(lbase, W[I][0]);                                                              \
+        fa[I & FS][2] = lut4p(lbase, W[I][2]);                                                              \
+        fa[I & FS][1] = lut4p(lbase, W[I][1]);                                                              \
+        fa[I & FS][3] = lut4p(lbase, W[I][3]);                                                              \
         LOAD(I)                                                                                             \
     }
 #define M355_MFMA(I)                                                                                        \
     {                                                                                                       \
         const float4_t z = {0.f, 0.f, 0.f, 0.f};                                                            \
-        pa = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], xb[I][0], z, 0, 0, 0);                           \
-        pb = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[2], xb[I][0], z, 0, 0, 0);                           \
-        pa = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], xb[I][1], pa, 0, 0, 0);                          \
-        pb = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[3], xb[I][1], pb, 0, 0, 0);                          \
+        pa[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][0], xb[I][0], z, 0, 0, 0);           \
+        pb[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][2], xb[I][0], z, 0, 0, 0);           \
+        pa[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][1], xb[I][1], pa[I & FS], 0, 0, 0);  \
+        pb[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][3], xb[I][1], pb[I & FS], 0, 0, 0);  \
     }
     // element 0 of each tile goes through instructions the compiler knows (so it places the MFMA-result wait
     // states); the other elements follow as single v_fmac_f32_dpp instructions that depend on element 0's result
 #define M355_SCALE(I)                                                                                       \
-    accA[0] += row_bcast<I>(sA[0]) * pa[0];                                                                  \
-    accB[0] += row_bcast<I>(sB[0]) * pb[0];                                                                  \
+    accA[0] += row_bcast<I>(sA[0]) * pa[I & FS][0];                                                          \
+    accB[0] += row_bcast<I>(sB[0]) * pb[I & FS][0];                                                          \
     _Pragma("unroll") for (int r = 1; r < 4; r++) {                                                         \
-        accA[r] = fmac_row_bcast_after<I>(accA[r], sA[r], pa[r], accA[0]);                                   \
-        accB[r] = fmac_row_bcast_after<I>(accB[r], sB[r], pb[r], accB[0]);                                   \
+        accA[r] = fmac_row_bcast_after<I>(accA[r], sA[r], pa[I & FS][r], accA[0]);                           \
+        accB[r] = fmac_row_bcast_after<I>(accB[r], sB[r], pb[I & FS][r], accB[0]);                           \
     }
 #ifdef M355_EXP_NOCOMPUTE   /* experiment: keep the loads, drop table lookups and MFMAs */
 #undef M355_FETCH
@@ -503,6 +512,20 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
 #define M355_SCALE(I) accA[0] += sA[0]; accB[0] += sB[0];
 #endif
 #define M355_BLOCK(I, LOAD) M355_FETCH(I, LOAD) M355_MFMA(I) M355_SCALE(I)
+    // pipelined form: lookups of block I+1, MFMAs of block I, scaling of block I-1 in one step, so the LDS and MFMA
+    // latencies of one block sit under the vector work of its neighbours
+#ifdef M355_GROUPS   /* per step: 4 x { 1 MFMA, 4 VALU, 4 LDS reads, 3 VALU } */
+#define M355_PIPE_HINT                                                                                      \
+    _Pragma("unroll") for (int h_ = 0; h_ < 4; h_++) {                                                      \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                  \
+    }
+#else
+#define M355_PIPE_HINT
+#endif
+#define M355_STEP(I, LOAD) M355_FETCH(I + 1, LOAD) M355_MFMA(I) M355_SCALE(I - 1) M355_PIPE_HINT
 
     // One work item.  LOAD is M355_LOAD while another item follows in this workgroup's range (the ring then refills
     // with it) and M355_NO_LOAD for the last one.
@@ -531,11 +554,18 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
         }                                                                                                   \
         if (MORE) M355_POINT_AT(it + 1)                                                                     \
         float4_t accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};                                  \
-        half8_t fa[4];                                                                                      \
-        float4_t pa, pb;                                                                                    \
-        M355_BLOCK(0, LOAD) M355_BLOCK(1, LOAD) M355_BLOCK(2, LOAD) M355_BLOCK(3, LOAD) M355_BLOCK(4, LOAD) \
-        M355_BLOCK(5, LOAD) M355_BLOCK(6, LOAD) M355_BLOCK(7, LOAD) M355_BLOCK(8, LOAD) M355_BLOCK(9, LOAD) \
-        M355_BLOCK(10, LOAD) M355_BLOCK(11, LOAD)                                                           \
+        half8_t fa[FS + 1][4];                                                                              \
+        float4_t pa[FS + 1], pb[FS + 1];                                                                    \
+        if (FS) {                                                                                           \
+            M355_FETCH(0, LOAD) M355_FETCH(1, LOAD) M355_MFMA(0)                                            \
+            M355_STEP(1, LOAD) M355_STEP(2, LOAD) M355_STEP(3, LOAD) M355_STEP(4, LOAD) M355_STEP(5, LOAD)  \
+            M355_STEP(6, LOAD) M355_STEP(7, LOAD) M355_STEP(8, LOAD) M355_STEP(9, LOAD) M355_STEP(10, LOAD) \
+            M355_MFMA(11) M355_SCALE(10) M355_SCALE(11)                                                     \
+        } else {                                                                                            \
+            M355_BLOCK(0, LOAD) M355_BLOCK(1, LOAD) M355_BLOCK(2, LOAD) M355_BLOCK(3, LOAD)                 \
+            M355_BLOCK(4, LOAD) M355_BLOCK(5, LOAD) M355_BLOCK(6, LOAD) M355_BLOCK(7, LOAD)                 \
+            M355_BLOCK(8, LOAD) M355_BLOCK(9, LOAD) M355_BLOCK(10, LOAD) M355_BLOCK(11, LOAD)               \
+        }                                                                                                   \
         sA = sAn;                                                                                           \
         sB = sBn;                                                                                           \
         /* sum the K-parts through LDS (two buffers in turn, so one barrier per item is enough) */          \
@@ -564,6 +594,8 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     M355_ITEM(it1 - 1, M355_NO_LOAD, false)
 #undef M355_ITEM
 #undef M355_BLOCK
+#undef M355_STEP
+#undef M355_PIPE_HINT
 #undef M355_SCALE
 #undef M355_MFMA
 #undef M355_FETCH
