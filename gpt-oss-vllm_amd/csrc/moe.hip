@@ -380,14 +380,147 @@ __device__ __forceinline__ void gemm_epilogue(const float4_t& accA, const float4
     }
 }
 
-template <int MODE, int PAIRS>
+// What a gate_up launch needs to bucket the (token, k) pairs by expert itself (INLINE), instead of reading the lists
+// a routing kernel left in the workspace: the raw expert ids, and where workgroup 0 leaves the lists for the kernels
+// that follow (down GEMM, combine).
+struct RouteIO {
+    const int32_t* ids;
+    int P, E_local, e_first;
+    int32_t *n_active, *offsets, *active, *sorted, *inv, *n_tiles, *tile_expert, *tile_m0;
+};
+constexpr int INLINE_MAX_P = 256;      // one pair per thread of the smallest workgroup
+constexpr int INLINE_MAX_E = 128;      // two experts per lane of the scanning wave
+constexpr int INLINE_MAX_TILES = 160;  // <= min(P, E) when T <= 16, else <= E + P / 16
+struct InlineTables {                  // lives in LDS behind the reduction buffers for the whole kernel
+    int32_t off[INLINE_MAX_E + 1];
+    int32_t tile_e[INLINE_MAX_TILES];
+    int32_t tile_m0[INLINE_MAX_TILES];
+    int32_t tok[INLINE_MAX_P];         // sorted position -> pair index
+    int32_t nt;
+};
+
+// Every workgroup buckets the pairs the same way (the result must not depend on timing: all of them address the
+// same h rows): per expert a bit mask of its pairs, built with LDS atomic ORs; a pair's place within its expert
+// is the number of lower-numbered pairs in the mask.  `masks` is scratch ([E_local][8] words).
+__device__ __forceinline__ void inline_route(const RouteIO& rio, int my_e, int mt_rows, uint32_t* masks, InlineTables* rt,
+                                             int tid, int threads) {
+    const int E = rio.E_local;
+    const bool scribe = blockIdx.x == 0;
+    for (int i = tid; i < E * 8; i += threads) masks[i] = 0;
+    __syncthreads();
+    if (my_e >= 0) atomicOr(&masks[my_e * 8 + (tid >> 5)], 1u << (tid & 31));
+    __syncthreads();
+    if (tid < 64) {
+        // wave 0: lane l owns experts 2l and 2l+1; exclusive wave scans give where their lists start
+        int c[2], s_cnt = 0, s_act = 0, s_tiles = 0;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int e = 2 * tid + j;
+            c[j] = 0;
+            if (e < E) {
+#pragma unroll
+                for (int w = 0; w < 8; w++) c[j] += __builtin_popcount(masks[e * 8 + w]);
+            }
+            s_cnt += c[j];
+            s_act += c[j] > 0;
+            s_tiles += (c[j] + mt_rows - 1) / mt_rows;
+        }
+        int run = s_cnt, na = s_act, nt = s_tiles;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int a1 = __shfl_up(run, o, 64), a2 = __shfl_up(na, o, 64), a3 = __shfl_up(nt, o, 64);
+            if (tid >= o) { run += a1; na += a2; nt += a3; }
+        }
+        if (tid == 63) {
+            rt->off[E] = run;
+            rt->nt = nt;
+            if (scribe) { rio.offsets[E] = run; *rio.n_active = na; *rio.n_tiles = nt; }
+        }
+        run -= s_cnt; na -= s_act; nt -= s_tiles;   // exclusive
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int e = 2 * tid + j;
+            if (e < E) {
+                rt->off[e] = run;
+                if (scribe) { rio.offsets[e] = run; if (c[j] > 0) rio.active[na] = e; }
+                na += c[j] > 0;
+                for (int m0 = 0; m0 < c[j]; m0 += mt_rows) {
+                    rt->tile_e[nt] = e;
+                    rt->tile_m0[nt] = m0;
+                    if (scribe) { rio.tile_expert[nt] = e; rio.tile_m0[nt] = m0; }
+                    nt++;
+                }
+                run += c[j];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < rio.P) {
+        int pos = -1;
+        if (my_e >= 0) {
+            const int chunk = tid >> 5;
+            int rank = __builtin_popcount(masks[my_e * 8 + chunk] & ((1u << (tid & 31)) - 1u));
+            for (int w = 0; w < chunk; w++) rank += __builtin_popcount(masks[my_e * 8 + w]);
+            pos = rt->off[my_e] + rank;
+            rt->tok[pos] = tid;
+            if (scribe) rio.sorted[pos] = tid;
+        }
+        if (scribe) rio.inv[tid] = pos;
+    }
+    __syncthreads();   // the lists are complete, and the mask area is free again
+}
+
+// 256 x 32 code table with 256-byte rows: entry (byte, replica) = half2(code[byte & 15], code[byte >> 4]).  The 16
+// codes come from immediates (a select chain in 16 threads, parked in `park`), not from memory.
+__device__ __forceinline__ void build_lutp(uint32_t* lut, unsigned char* park, int tid, int threads) {
+    half_t* codes = reinterpret_cast<half_t*>(park);
+    if (tid < 16) {
+        const float tab[16] = M355_NF4_TABLE;
+        float c = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) c = (tid == j) ? tab[j] : c;
+        codes[tid] = (half_t)c;
+    }
+    lds_barrier();
+    for (int i = tid; i < 256 * 32; i += threads) {   // 32 replicas (one per bank) in each 256-byte row
+        const int bv = i >> 5;
+        const half2_t hv = {codes[bv & 15], codes[bv >> 4]};
+        lut[bv * 64 + (i & 31)] = __builtin_bit_cast(uint32_t, hv);
+    }
+    lds_barrier();   // park is free again: everyone is done reading the codes
+}
+
+template <int MODE, int PAIRS, bool INLINE>
 __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     const half_t* __restrict__ xin, const uint8_t* __restrict__ wq, const float* __restrict__ wam,
     const int32_t* __restrict__ n_tiles, const int32_t* __restrict__ tile_expert, const int32_t* __restrict__ tile_m0,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ sorted, int K, int R, int k_top, int mt_rows,
-    half_t* __restrict__ outp) {
+    half_t* __restrict__ outp, int table_len, RouteIO rio) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int THREADS = PAIRS * 256;
+    constexpr int RED_ALL = 2 * PAIRS * (MOE_KPARTS - 1) * 64 * 8 * 4;   // both reduction buffers
+    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
+    unsigned char* red = smem + LUTP_BYTES;
+    InlineTables* rt = reinterpret_cast<InlineTables*>(red + RED_ALL);
+    int te_lane = 0;
+    if constexpr (INLINE) {
+        // the ids are requested first; the code table is built while they are on their way
+        int my_e = -1;
+        if ((int)threadIdx.x < rio.P) my_e = rio.ids[threadIdx.x] - rio.e_first;
+        build_lutp(lut, red, threadIdx.x, THREADS);
+        if (my_e >= rio.E_local) my_e = -1;
+        inline_route(rio, my_e, mt_rows, reinterpret_cast<uint32_t*>(red), rt, threadIdx.x, THREADS);
+    } else {
+        // The first 64 entries of the tile -> expert table are requested right away, one per lane, together with
+        // the tile count, so the first weight address is one memory round trip away instead of two; later lookups
+        // of those entries are lane reads.
+        te_lane = ((int)(threadIdx.x & 63) < table_len) ? tile_expert[threadIdx.x & 63] : 0;
+    }
+#define M355_TILE_EXPERT(TT) (INLINE ? __builtin_amdgcn_readfirstlane(rt->tile_e[(TT)]) \
+                                     : (((TT) < 64) ? __builtin_amdgcn_readlane(te_lane, (TT)) : tile_expert[(TT)]))
+#define M355_TILE_M0(TT) (INLINE ? __builtin_amdgcn_readfirstlane(rt->tile_m0[(TT)]) : tile_m0[(TT)])
+#define M355_OFFSET(E) (INLINE ? __builtin_amdgcn_readfirstlane(rt->off[(E)]) : offsets[(E)])
+#define M355_PAIR_AT(POS) (INLINE ? rt->tok[(POS)] : sorted[(POS)])
     constexpr int RED1 = PAIRS * (MOE_KPARTS - 1) * 64 * 8 * 4;   // one reduction buffer
 #ifndef M355_FS
 #define M355_FS 0
@@ -396,13 +529,10 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     const int NB = K / 64, NP = R / 32;
     const int NPG = (NP + PAIRS - 1) / PAIRS;
     // work item = (token tile of one expert, group of PAIRS row-tile pairs); a workgroup takes a contiguous range
-    const int total = *n_tiles * NPG;
+    const int total = (INLINE ? __builtin_amdgcn_readfirstlane(rt->nt) : *n_tiles) * NPG;
     const int it0 = (int)((int64_t)blockIdx.x * total / gridDim.x);
     const int it1 = (int)((int64_t)(blockIdx.x + 1) * total / gridDim.x);
     if (it0 >= it1) return;
-
-    uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
-    unsigned char* red = smem + LUTP_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -429,7 +559,7 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
 #define M355_POINT_AT(IT)                                                                                     \
     {                                                                                                         \
         const int tt_ = (IT) / NPG, pg_ = (IT) - tt_ * NPG;                                                   \
-        const int e_ = tile_expert[tt_];                                                                      \
+        const int e_ = M355_TILE_EXPERT(tt_);                                                                 \
         const int pc_ = min(pg_ * PAIRS + pl, NP - 1);                                                        \
         wbase_next = wq + (size_t)e_ * wq_expert + ((size_t)pc_ * NB + bq0) * 1024;                           \
         const float4_t* am_ = reinterpret_cast<const float4_t*>(wam + (size_t)e_ * am_expert);                \
@@ -453,25 +583,7 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     sA = sAn;
     sB = sBn;
 
-    // code table: entry (byte, replica) = half2(code[byte & 15], code[byte >> 4]).  The 16 codes come from
-    // immediates (a select chain in 16 threads, parked at the start of the reduction area), not from memory.
-    {
-        half_t* codes = reinterpret_cast<half_t*>(red);
-        if (tid < 16) {
-            const float tab[16] = M355_NF4_TABLE;
-            float c = 0.f;
-#pragma unroll
-            for (int j = 0; j < 16; j++) c = (tid == j) ? tab[j] : c;
-            codes[tid] = (half_t)c;
-        }
-        lds_barrier();
-        for (int i = tid; i < 256 * 32; i += THREADS) {   // 32 replicas (one per bank) in each 256-byte row
-            const int bv = i >> 5;
-            const half2_t hv = {codes[bv & 15], codes[bv >> 4]};
-            lut[bv * 64 + (i & 31)] = __builtin_bit_cast(uint32_t, hv);
-        }
-        lds_barrier();   // codes sits in the reduction area: everyone is done reading it before the first item
-    }
+    if constexpr (!INLINE) build_lutp(lut, red, tid, THREADS);   // (while the first weights are on their way)
     const uint32_t lbase = lutp_lane_base(smem, lane);
 
     // Every wave runs MOE_CHUNK blocks per item without branches.  Per block: M355_FETCH (16 table lookups = four A
@@ -533,17 +645,17 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     {                                                                                                       \
         const int it = (IT);                                                                                \
         const int tt = it / NPG, pg = it - tt * NPG;                                                        \
-        const int e = tile_expert[tt];                                                                      \
-        const int m0 = tile_m0[tt];                                                                         \
-        const int pos0 = offsets[e] + m0;                                                                   \
-        const int mt = min(mt_rows, offsets[e + 1] - pos0);                                                 \
+        const int e = M355_TILE_EXPERT(tt);                                                                 \
+        const int m0 = M355_TILE_M0(tt);                                                                    \
+        const int pos0 = M355_OFFSET(e) + m0;                                                               \
+        const int mt = min(mt_rows, M355_OFFSET(e + 1) - pos0);                                             \
         const int p = pg * PAIRS + pl;                                                                      \
         const bool live = p < NP;                                                                           \
         if (tt != staged_tile) {                                                                            \
             /* this lane's B fragments of the whole K-part: token row n (clamped), columns 64b + 16g .. + 15 */ \
             /* of each block, from global memory into registers, where they stay until the token tile changes */ \
             const int pos = pos0 + min(n, mt - 1);                                                          \
-            const int64_t src_row = (MODE == 0) ? (int64_t)(sorted[pos] / k_top) : (int64_t)pos;            \
+            const int64_t src_row = (MODE == 0) ? (int64_t)(M355_PAIR_AT(pos) / k_top) : (int64_t)pos;      \
             const u32x4_t* src = reinterpret_cast<const u32x4_t*>(xin + src_row * K) + 2 * g;               \
             _Pragma("unroll") for (int i = 0; i < MOE_CHUNK; i++) {                                         \
                 const int bb = min(bq0 + i, blast);                                                         \
@@ -593,6 +705,10 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     for (int itx = it0; itx < it1 - 1; itx++) M355_ITEM(itx, M355_LOAD, true)
     M355_ITEM(it1 - 1, M355_NO_LOAD, false)
 #undef M355_ITEM
+#undef M355_TILE_EXPERT
+#undef M355_TILE_M0
+#undef M355_OFFSET
+#undef M355_PAIR_AT
 #undef M355_BLOCK
 #undef M355_STEP
 #undef M355_PIPE_HINT
@@ -656,10 +772,12 @@ static int device_setup(int dev, int* cus) {
     if (!done[d]) {
         if (int rc = allow_big_lds(&moe_gemm_kernel<0>)) return rc;
         if (int rc = allow_big_lds(&moe_gemm_kernel<1>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 1>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 2>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1, false>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2, false>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1, true>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2, true>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 1, false>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 2, false>)) return rc;
         int v = 0;
         if (int rc = hip_status(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute")) return rc;
         ncu[d] = v > 0 ? v : 256;
@@ -669,32 +787,38 @@ static int device_setup(int dev, int* cus) {
     return 0;
 }
 
-static int stream_lds_bytes(int K, int mt_rows, int pairs) {
-    (void)K; (void)mt_rows;   // activations live in registers
-    return LUTP_BYTES + 2 * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4;
+static int stream_lds_bytes(int pairs, bool inline_route) {   // (activations live in registers)
+    return LUTP_BYTES + 2 * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4 + (inline_route ? (int)align_up(sizeof(InlineTables), 16) : 0);
+}
+
+// A gate_up launch can bucket the pairs itself when a pair per thread and two experts per lane cover them.
+static bool can_route_inline(int P, int E_local, int K) {
+    return K / 64 <= MOE_KPARTS * MOE_CHUNK && P <= INLINE_MAX_P && E_local <= INLINE_MAX_E;
 }
 
 // W [R][K] per expert.  K <= 48 blocks: streaming kernel, one or two workgroups per CU; else the general kernel.
-template <int MODE>
+// `rio` non-null (gate_up only): the kernel buckets the pairs itself and leaves the lists in the workspace.
+template <int MODE, bool INLINE>
 static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, const MoeWorkspace& ws, int K, int R,
-                       int k_top, int mt_rows, int slots, half_t* outp, int cus, hipStream_t st) {
+                       int k_top, int mt_rows, int slots, half_t* outp, int cus, hipStream_t st, const RouteIO& rio) {
     const int NP = R / 32, NB = K / 64;
     if (NB <= MOE_KPARTS * MOE_CHUNK) {
         // upper bound of sum_e ceil(M_e / mt_rows): with T <= 16 a token tile holds a whole expert (M_e <= T = mt_rows)
         const int max_tiles = (ws.max_pairs / k_top <= MOE_MAX_MT) ? slots : slots + ws.max_pairs / mt_rows;
         const int items2 = max_tiles * ((NP + 1) / 2);
+        const int table_len = ws.max_pairs + slots < 64 ? ws.max_pairs + slots : 64;   // the table holds P + E_local entries
         if (2 * items2 >= cus) {   // 8-wave workgroups unless even those would leave most CUs idle
-            const int lds = stream_lds_bytes(K, mt_rows, 2);
+            const int lds = stream_lds_bytes(2, INLINE);
             const int grid = items2 < cus ? items2 : cus;
-            moe_gemm_stream_kernel<MODE, 2><<<dim3(grid), dim3(512), lds, st>>>(xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0,
-                                                                                ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp);
+            moe_gemm_stream_kernel<MODE, 2, INLINE><<<dim3(grid), dim3(512), lds, st>>>(
+                xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio);
         } else {
-            const int lds = stream_lds_bytes(K, mt_rows, 1);
+            const int lds = stream_lds_bytes(1, INLINE);
             const int per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
             const int items1 = max_tiles * NP;
             const int grid = items1 < per_cu * cus ? items1 : per_cu * cus;
-            moe_gemm_stream_kernel<MODE, 1><<<dim3(grid), dim3(256), lds, st>>>(xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0,
-                                                                                ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp);
+            moe_gemm_stream_kernel<MODE, 1, INLINE><<<dim3(grid), dim3(256), lds, st>>>(
+                xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio);
         }
         M355_LAUNCH_CHECK("moe_gemm_stream_kernel");
         return 0;
@@ -743,17 +867,22 @@ extern "C" int m355_moe_nf4_forward(const void* x_f16, int T, const int32_t* ids
     if (gemm_lds_bytes(H, mt_rows) > 160 * 1024 || gemm_lds_bytes(FF, mt_rows) > 160 * 1024)
         return fail(-2, "m355_moe_nf4_forward: H or FF too large for the LDS activation tile");
 
-    if (!(flags & M355_FLAG_SKIP_ROUTE)) {
+    // gate_up buckets the pairs itself when it can; the routing kernel runs when it cannot, or when gate_up is skipped
+    const bool inline_route = can_route_inline(P, E_local, H) && !(flags & M355_FLAG_SKIP_GATE_UP);
+    const RouteIO rio = {ids, P, E_local, e_first, ws.n_active, ws.offsets, ws.active, ws.sorted, ws.inv, ws.n_tiles, ws.tile_expert, ws.tile_m0};
+    if (!(flags & M355_FLAG_SKIP_ROUTE) && !inline_route) {
         moe_route_kernel<<<dim3(1), dim3(ROUTE_THREADS), 0, st>>>(ids, P, E_local, e_first, ws.n_active, ws.offsets,
                                                                   ws.active, ws.sorted, ws.inv, mt_rows, ws.n_tiles,
                                                                   ws.tile_expert, ws.tile_m0);
         M355_LAUNCH_CHECK("moe_route_kernel");
     }
     if (!(flags & M355_FLAG_SKIP_GATE_UP)) {
-        if (int rc = launch_gemm<0>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st)) return rc;
+        if (int rc = inline_route ? launch_gemm<0, true>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio)
+                                  : launch_gemm<0, false>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio))
+            return rc;
     }
     if (!(flags & M355_FLAG_SKIP_DOWN)) {
-        if (int rc = launch_gemm<1>(ws.h, w2_q, w2_absmax, ws, FF, H, k, mt_rows, slots, ws.y, cus, st)) return rc;
+        if (int rc = launch_gemm<1, false>(ws.h, w2_q, w2_absmax, ws, FF, H, k, mt_rows, slots, ws.y, cus, st, rio)) return rc;
     }
     if (!(flags & M355_FLAG_SKIP_COMBINE)) {
         moe_combine_kernel<<<dim3(T), dim3(256), 0, st>>>(ws.y, ws.inv, w, H, k, (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0,
