@@ -194,6 +194,34 @@ def test_moe_expert_shards_sum_to_whole(ref, m355, cuda):
     _close(whole.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("T,E,k", [(150, 8, 2), (5, 160, 4), (64, 32, 4), (65, 32, 4)])
+def test_moe_routing_paths_vs_oracle(T, E, k, ref, m355, cuda):
+    """Pairs are bucketed inside the gate_up launch up to 256 pairs / 128 local experts and by the routing kernel
+    beyond that: both sides of each limit against the oracle, and the stage-by-stage call (route, gate_up, down,
+    combine as four calls with skip flags) against the one-call result, bit for bit."""
+    H, FF = 256, 192
+    sd = ref.stream_seed(T, E, k, 991)
+    layer = ref.synth_layer(sd, E, H, FF)
+    x = ref.normal_f16(ref.stream_seed(sd, 1), (T, H))
+    lg = ref.normal_f16(ref.stream_seed(sd, 2), (T, E), 1.5)
+    ids, w = m355.topk_softmax(_to_dev(lg, cuda), k)
+    tl = tiled_layer(m355, layer, E, H, FF, cuda)
+    xd = _to_dev(x, cuda)
+    out = m355.moe_nf4_forward(xd, ids, w, *tl, E_local=E, e_first=0, H=H, FF=FF)
+    torch.cuda.synchronize()
+    want = ref.moe_forward(x, ids.cpu().numpy(), w.cpu().numpy(), **layer, E_local=E, H=H, FF=FF)
+    _close(out.cpu().numpy(), want)
+    ws = torch.empty(m355.moe_workspace_bytes(T, k, H, FF, E), dtype=torch.uint8, device=cuda)
+    staged = torch.empty_like(out)
+    F = m355.FLAG_FP16_COMBINE
+    every = m355.FLAG_SKIP_ROUTE | m355.FLAG_SKIP_GATE_UP | m355.FLAG_SKIP_DOWN | m355.FLAG_SKIP_COMBINE
+    for keep in (m355.FLAG_SKIP_ROUTE, m355.FLAG_SKIP_GATE_UP, m355.FLAG_SKIP_DOWN, m355.FLAG_SKIP_COMBINE):
+        m355.moe_nf4_forward(xd, ids, w, *tl, E_local=E, e_first=0, H=H, FF=FF, flags=F | (every & ~keep),
+                             workspace=ws, out=staged)
+    torch.cuda.synchronize()
+    assert torch.equal(staged, out)
+
+
 def test_moe_empty_batch_and_errors(m355, cuda):
     z = torch.zeros(256, dtype=torch.uint8, device=cuda)
     f = torch.zeros(64, dtype=torch.float32, device=cuda)
