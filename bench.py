@@ -31,6 +31,23 @@ HQ, HKV, D, BLOCK = 64, 8, 64, 16
 GATE_UP_BYTES = (2 * FF * H) // 2 + (2 * FF * H) // 64      # packed codes + 1 B absmax per 64: 8,553,600
 DOWN_BYTES = (H * FF) // 2 + (H * FF) // 64                  # 4,276,800
 HBM_PEAK_GBS = 8000.0
+MFMA_PEAK_TFLOPS = 2500.0    # dense fp16
+GATE_UP_FLOPS_PER_PAIR = 2 * 2 * FF * H   # one (token, expert) pair through W13
+
+
+def profiled_traffic():
+    """HBM bytes per gate_up launch from the newest committed counter profile (profiles/rNN_traffic.json, written by
+    profiles/summarize.py from separate rocprofv3 --pmc passes): counters cannot be read from inside this run."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return d.get("gate_up_hbm_bytes_per_launch"), os.path.basename(files[-1])
+    except (OSError, ValueError):
+        return None, None
 
 
 class DecodeStep:
@@ -282,13 +299,18 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_roofline:
         r, active = roofline_gate_up(main_step)
+        traffic, traffic_src = profiled_traffic()
+        tflops = a.batch_per_gpu * TOPK * GATE_UP_FLOPS_PER_PAIR / (r["gate_up"]["avg_us"] * 1e-6) / 1e12
         result["roofline"] = {
-            "bound": "hbm", "kernel": "moe_gemm_kernel<0> (gate_up)", "achieved": r["gate_up"]["gbs"], "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": r["gate_up"]["gbs"] / HBM_PEAK_GBS, "traffic": None,
+            "bound": "hbm", "kernel": "moe_gemm_stream_kernel<gate_up> (NF4 dequant fused into the grouped GEMM)",
+            "achieved": r["gate_up"]["gbs"], "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": r["gate_up"]["gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "avg_us": r["gate_up"]["avg_us"], "algorithmic_bytes_per_launch": r["gate_up"]["bytes"],
             "mean_active_experts": sum(active) / len(active),
             "down_kernel": {"achieved": r["down"]["gbs"], "avg_us": r["down"]["avg_us"],
                             "frac": r["down"]["gbs"] / HBM_PEAK_GBS},
+            # the same launch priced against the matrix cores: decode at 4 tokens per expert is far left of the ridge
+            "mfma": {"achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS},
         }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()

@@ -54,4 +54,11 @@ with open(f"profiles/{tag}_summary.md", "w") as out:
             out.write(f"| {k[0]} | {k[1]} | {len(v)} | {sum(v) / len(v):.6g} |\n")
         out.write("\nTCC_EA0_RDREQ counts 128-byte requests here (no 32-byte ones); FETCH_SIZE is in KiB and reads one half of a "
                   "wide coalesced stream on gfx950, so bytes = 2 x FETCH_SIZE x 1024 = RDREQ x 128.\n")
+rd = pmc.get(("gate_up", "TCC_EA0_RDREQ_sum"))
+rd_down = pmc.get(("down", "TCC_EA0_RDREQ_sum"))
+if rd:
+    with open(f"profiles/{tag}_traffic.json", "w") as out:
+        json.dump({"gate_up_hbm_bytes_per_launch": sum(rd) / len(rd) * 128,
+                   "down_hbm_bytes_per_launch": (sum(rd_down) / len(rd_down) * 128) if rd_down else None,
+                   "source": "TCC_EA0_RDREQ_sum x 128 B, rocprofv3 --pmc pass over scratch/prof_moe.py (bs=32)"}, out, indent=1)
 print(open(f"profiles/{tag}_summary.md").read()[:3000])
