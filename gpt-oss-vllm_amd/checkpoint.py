@@ -14,7 +14,20 @@ from typing import Dict, Iterable, Iterator, List, Optional, Tuple
 import torch
 
 PROJ_KEYS = {"gate_up": "gate_up_projs", "down": "down_projs"}
-STATE_SUFFIXES = ("absmax", "nested_absmax", "nested_quant_map", "quant_map")
+STATE_SUFFIXES = ("absmax", "nested_absmax", "nested_quant_map", "quant_map", "quant_state.bitsandbytes__nf4")
+
+
+def discover_shards(cache_dir: Optional[str] = None) -> List[str]:
+    """The safetensors shards of an Unsloth gpt-oss checkpoint in the Hugging Face cache, found the way
+    patches/patch_11_consolidate_unsloth.py:36-43 finds them: first any `models--*unsloth*gpt-oss*` snapshot,
+    then the 20b 4-bit repository by name; sorted, possibly empty."""
+    import glob
+    import os
+    root = os.path.expanduser(cache_dir if cache_dir is not None else "~/.cache/huggingface/hub/")
+    files = sorted(glob.glob(os.path.join(root, "models--*unsloth*gpt-oss*/snapshots/*/*.safetensors")))
+    if not files:
+        files = sorted(glob.glob(os.path.join(root, "models--unsloth--gpt-oss-20b-unsloth-bnb-4bit/snapshots/*/*.safetensors")))
+    return files
 
 
 def expert_weight_key(layer_idx: int, expert_idx: int, proj: str) -> str:

@@ -12,6 +12,7 @@ forward raises if the HIP library or the GPU is missing.
 """
 from __future__ import annotations
 
+import json
 from typing import Any, Dict, List, Optional
 
 import torch
@@ -64,13 +65,61 @@ def resolve_absmax(absmax: Optional[torch.Tensor], nested_absmax: Optional[torch
 
 
 # ---------------------------------------------------------------------------------------------
+# "true_bnb" layout: a tensor read the way bitsandbytes itself reads it, not the way the reference's loader does
+# ---------------------------------------------------------------------------------------------
+NF4_CODE = (-1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453, -0.28444138169288635,
+            -0.18477343022823334, -0.09105003625154495, 0.0, 0.07958029955625534, 0.16093020141124725,
+            0.24611230194568634, 0.33791524171829224, 0.44070982933044434, 0.5626170039176941,
+            0.7229568362236023, 1.0)     # the table of patches/streaming_unsloth_bnb.py:101-106 (= bitsandbytes' NF4)
+BNB_NESTED_BLOCK = 256
+QUANT_STATE_SUFFIX = "quant_state.bitsandbytes__nf4"
+
+
+def parse_quant_state(blob: Optional[torch.Tensor]) -> Dict[str, Any]:
+    """The JSON bitsandbytes packs into `<weight>.quant_state.bitsandbytes__nf4` (a uint8 tensor):
+    quant_type, blocksize, dtype, shape, nested_blocksize, nested_offset, ..."""
+    if blob is None:
+        return {}
+    raw = bytes(blob.detach().cpu().to(torch.uint8).reshape(-1).tolist())
+    try:
+        return json.loads(raw.decode("utf-8"))
+    except (UnicodeDecodeError, ValueError) as exc:
+        raise ValueError(f"unreadable {QUANT_STATE_SUFFIX}: {exc}") from None
+
+
+def resolve_absmax_bnb(absmax: torch.Tensor, nested_absmax: Optional[torch.Tensor],
+                       nested_quant_map: Optional[torch.Tensor], nested_offset: float,
+                       nested_blocksize: int = BNB_NESTED_BLOCK) -> torch.Tensor:
+    """bitsandbytes' own un-double-quantisation: absmax[b] = code[absmax_u8[b]] * nested_absmax[b // 256] + offset
+    (the reference instead multiplies by nested_absmax.mean() and never adds the offset,
+    patches/streaming_unsloth_bnb.py:148-171)."""
+    if nested_absmax is None:
+        return absmax.detach().cpu().float().reshape(-1)
+    if nested_quant_map is None:
+        raise ValueError("nested_absmax needs nested_quant_map")
+    a = nested_quant_map.detach().cpu().float()[absmax.detach().cpu().to(torch.uint8).long().reshape(-1)]
+    scale = nested_absmax.detach().cpu().float().reshape(-1).repeat_interleave(nested_blocksize)[:a.numel()]
+    if scale.numel() != a.numel():
+        raise ValueError(f"{nested_absmax.numel()} nested scales cannot cover {a.numel()} absmax codes")
+    return a * scale + float(nested_offset)
+
+
+# ---------------------------------------------------------------------------------------------
 # QuantizationConfig
 # ---------------------------------------------------------------------------------------------
 class Mi355Nf4MoEConfig(_QConfigBase):
     """4-bit NF4 for the MoE experts only; router and attention stay fp16 (patches/bnb_moe_4bit.py:22-56)."""
 
-    def __init__(self):
+    LAYOUTS = ("reference", "true_bnb")
+
+    def __init__(self, layout: str = "reference"):
+        """layout "reference": tensors are read as the reference's loader reads them (low nibble first, mean
+        fallback for the nested scales, no offset) -- the parity contract.  "true_bnb": as bitsandbytes wrote
+        them (high nibble first, one nested scale per 256 blocks, plus nested_offset)."""
         super().__init__()
+        if layout not in self.LAYOUTS:
+            raise ValueError(f"layout {layout!r}: expected one of {self.LAYOUTS}")
+        self.layout = layout
         self.weight_bits = 4
         self.group_size = BLOCKSIZE
         self.compute_dtype = torch.float16
@@ -94,7 +143,7 @@ class Mi355Nf4MoEConfig(_QConfigBase):
 
     @classmethod
     def from_config(cls, config: Dict[str, Any]) -> "Mi355Nf4MoEConfig":
-        return cls()
+        return cls(layout=(config or {}).get("layout", "reference"))
 
     def get_scaled_act_names(self) -> List[str]:
         return []
@@ -122,7 +171,7 @@ def get_moe_weight_names(model) -> List[str]:
 # ---------------------------------------------------------------------------------------------
 # FusedMoE method
 # ---------------------------------------------------------------------------------------------
-_SUFFIXES = ("nested_quant_map", "nested_absmax", "quant_map", "absmax")
+_SUFFIXES = (QUANT_STATE_SUFFIX, "nested_quant_map", "nested_absmax", "quant_map", "absmax")
 
 
 class Mi355Nf4MoEMethod(_MoEMethodBase):
@@ -201,7 +250,21 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
             q = t["weight"].reshape(-1).to(torch.uint8)
             if q.numel() * 2 != rows * cols:
                 raise ValueError(f"expert {e} {proj}: {q.numel()} packed bytes, expected {rows * cols // 2}")
-            am = resolve_absmax(t.get("absmax"), t.get("nested_absmax"), t.get("nested_quant_map")).reshape(-1)
+            if self.quant_config.layout == "true_bnb":
+                state = parse_quant_state(t.get(QUANT_STATE_SUFFIX))
+                if state.get("quant_type", "nf4") != "nf4" or int(state.get("blocksize", BLOCKSIZE)) != BLOCKSIZE:
+                    raise ValueError(f"expert {e} {proj}: quant_state {state} is not NF4 with blocksize {BLOCKSIZE}")
+                if "quant_map" in t and not torch.equal(t["quant_map"].detach().cpu().float().reshape(-1),
+                                                        torch.tensor(NF4_CODE, dtype=torch.float32)):
+                    raise ValueError(f"expert {e} {proj}: quant_map is not the NF4 table the kernels hold")
+                if t.get("absmax") is None:
+                    raise ValueError(f"expert {e} {proj}: no absmax")
+                am = resolve_absmax_bnb(t["absmax"], t.get("nested_absmax"), t.get("nested_quant_map"),
+                                        float(state.get("nested_offset", 0.0)),
+                                        int(state.get("nested_blocksize", BNB_NESTED_BLOCK))).reshape(-1)
+                q = (q >> 4) | (q << 4)      # the kernels take the low nibble first
+            else:
+                am = resolve_absmax(t.get("absmax"), t.get("nested_absmax"), t.get("nested_quant_map")).reshape(-1)
             if am.numel() * BLOCKSIZE != rows * cols:
                 raise ValueError(f"expert {e} {proj}: {am.numel()} absmax entries, the kernels need one per {BLOCKSIZE}")
             qt, at = lib.repack_nf4(q.to(dev).contiguous(), am.float().to(dev).contiguous(), rows, cols)

@@ -189,6 +189,64 @@ def nf4_dequant_numpy(q, n_params: int, absmax_f32) -> np.ndarray:
 
 
 # ---------------------------------------------------------------------------------------------
+# bitsandbytes' own NF4 layout (the "true_bnb" loader mode).  bitsandbytes is not installed here and the
+# reference never reads a tensor this way (its loader takes the low nibble first and ignores nested_offset,
+# patches/streaming_unsloth_bnb.py:148-190), so this restates the published algorithm of bitsandbytes 0.4x
+# `quantize_4bit` / `dequantize_4bit` with compress_statistics=True -- parity unpinned: no fixture of the
+# reference covers it; the tests check quantise -> store -> load -> dequantise round trips instead.
+#   element 2i   = code[byte >> 4], element 2i+1 = code[byte & 15]       (high nibble first)
+#   absmax[b]    = nested_code[absmax_u8[b]] * nested_absmax[b // 256] + nested_offset
+#   w            = fp16(code * absmax[block])                              (fp32 product, one rounding)
+# ---------------------------------------------------------------------------------------------
+BNB_NESTED_BLOCK = 256
+
+
+def bnb_dynamic_map() -> np.ndarray:
+    """A monotone signed 256-entry fp32 codebook in [-1, 1] with a dense centre, shaped like bitsandbytes'
+    dynamic map (the loader only ever looks values up in the table a checkpoint carries)."""
+    i = np.arange(256, dtype=np.float64)
+    v = np.sign(i - 127.5) * (np.abs(i - 127.5) / 127.5) ** 2.0
+    v[255] = 1.0
+    return np.sort(v).astype(np.float32)
+
+
+def bnb_resolve_absmax(absmax_u8, nested_map, nested_absmax, nested_offset: float) -> np.ndarray:
+    a = np.asarray(nested_map, dtype=np.float32)[np.asarray(absmax_u8, dtype=np.uint8).reshape(-1)]
+    scale = np.repeat(np.asarray(nested_absmax, dtype=np.float32).reshape(-1), BNB_NESTED_BLOCK)[:a.size]
+    return (a * scale + np.float32(nested_offset)).astype(np.float32)
+
+
+def bnb_swap_nibbles(q) -> np.ndarray:
+    q = np.asarray(q, dtype=np.uint8)
+    return ((q >> 4) | (q << 4)).astype(np.uint8)
+
+
+def bnb_nf4_dequant(q, n_params: int, absmax_f32, blocksize: int = 64) -> np.ndarray:
+    """fp16 weights of a high-nibble-first NF4 tensor (bitsandbytes dequantize_4bit)."""
+    return nf4_dequant_numpy(bnb_swap_nibbles(np.asarray(q).reshape(-1)), n_params, absmax_f32)
+
+
+def bnb_quantize_nf4(w_f32, blocksize: int = 64, nested_map=None):
+    """Quantise a flat fp32 array as bitsandbytes' quantize_4bit(quant_type='nf4', compress_statistics=True):
+    returns (packed u8 [n/2], absmax_u8 [n/blocksize], nested_absmax f32 [ceil(nblk/256)], nested_map, offset)."""
+    w = np.asarray(w_f32, dtype=np.float32).reshape(-1, blocksize)
+    absmax = np.abs(w).max(axis=1).astype(np.float32)
+    norm = w / np.maximum(absmax, np.float32(1e-30))[:, None]
+    idx = np.abs(norm[..., None] - NF4_QUANT_MAP[None, None, :]).argmin(axis=-1).astype(np.uint8).reshape(-1)
+    packed = ((idx[0::2] << 4) | idx[1::2]).astype(np.uint8)
+    nested_map = bnb_dynamic_map() if nested_map is None else np.asarray(nested_map, dtype=np.float32)
+    offset = np.float32(absmax.mean())
+    centred = absmax - offset
+    nblk = centred.size
+    pad = (-nblk) % BNB_NESTED_BLOCK
+    c2 = np.concatenate([centred, np.zeros(pad, np.float32)]).reshape(-1, BNB_NESTED_BLOCK)
+    nested_absmax = np.abs(c2).max(axis=1).astype(np.float32)
+    n2 = c2 / np.maximum(nested_absmax, np.float32(1e-30))[:, None]
+    a8 = np.abs(n2[..., None] - nested_map[None, None, :]).argmin(axis=-1).astype(np.uint8).reshape(-1)[:nblk]
+    return packed, a8, nested_absmax, nested_map, float(offset)
+
+
+# ---------------------------------------------------------------------------------------------
 # Synthetic inputs (self-contained PRNG so the GPU box rebuilds identical bytes)
 # ---------------------------------------------------------------------------------------------
 def stream_seed(*parts: int) -> int:
