@@ -222,6 +222,40 @@ def cpu_baseline():
     }
 
 
+def load_leg(device):
+    """Checkpoint -> GPU-resident tile-order weights for one full-size layer (32 experts): a synthetic shard in the
+    Unsloth key schema is written to a temporary directory, then read through the plug-in's weight_loader and
+    process_weights_after_loading (un-double-quantise absmax, upload packed blocks, repack on the GPU)."""
+    import tempfile
+    import numpy as np
+    from safetensors.torch import save_file
+    from gpt_oss_vllm_amd import checkpoint, plugin
+    rng = np.random.default_rng(355)
+    nmap = torch.linspace(-1, 1, 256)
+    tensors = {}
+    for e in range(E):
+        for proj, n in (("gate_up", 2 * FF * H), ("down", H * FF)):
+            key = checkpoint.expert_weight_key(0, e, proj)
+            tensors[key] = torch.from_numpy(rng.integers(0, 256, n // 2, dtype=np.uint8)).reshape(-1, 1)
+            tensors[key + ".absmax"] = torch.from_numpy(rng.integers(0, 256, n // 64, dtype=np.uint8))
+            tensors[key + ".nested_absmax"] = torch.full(((n // 64 + 255) // 256,), 0.03)
+            tensors[key + ".nested_quant_map"] = nmap.clone()
+    with tempfile.TemporaryDirectory() as d:
+        shard = os.path.join(d, "model-00001-of-00001.safetensors")
+        save_file(tensors, shard)
+        del tensors
+        method = plugin.Mi355Nf4MoEConfig().get_quant_method(None, "model.layers.0.mlp.experts")
+        layer = torch.nn.Module()
+        method.create_weights(layer, E, H, FF, torch.float16, device=device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        checkpoint.load_layer(method, layer, [shard], 0)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"seconds_per_layer": dt, "seconds_24_layers": dt * LAYERS,
+            "what": "one 32-expert layer from a local safetensors shard (page cache warm) to repacked GPU tensors"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -234,6 +268,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bs1", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--load-leg", action="store_true", help="also time checkpoint -> GPU weights for one layer")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -314,6 +349,8 @@ def main():
         }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
+    if rank == 0 and world == 1 and a.load_leg:
+        result["load"] = load_leg(device)
 
     if rank == 0:
         print(json.dumps(result), flush=True)
