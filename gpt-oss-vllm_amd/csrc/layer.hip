@@ -1,0 +1,143 @@
+// The small per-token operators that sit between the hot-path kernels in a gpt-oss decoder layer: residual add +
+// RMSNorm, and rotary embedding + KV-cache write.  Both are a few KB per token: latency, not bandwidth.
+// Arithmetic follows transformers' modeling_gpt_oss.py (GptOssRMSNorm.forward, _apply_rotary_emb) operation by
+// operation, with fp16 tensors where that code has model-dtype tensors, so every intermediate rounds where theirs does.
+#include "common.h"
+
+namespace m355 {
+
+constexpr int NORM_THREADS = 256;
+
+// r = fp16(x + delta) (or x); y = fp16(w * (float(r) * rsqrt(mean(float(r)^2) + eps))).  One workgroup per token.
+__global__ __launch_bounds__(NORM_THREADS) void add_rmsnorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ delta,
+                                                                   const half_t* __restrict__ weight, float eps, int H,
+                                                                   half_t* __restrict__ resid_out, half_t* __restrict__ y) {
+    __shared__ float part[NORM_THREADS / 64];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int chunks = H / 8;
+    const half8_t* xr = reinterpret_cast<const half8_t*>(x + (int64_t)t * H);
+    const half8_t* dr = delta ? reinterpret_cast<const half8_t*>(delta + (int64_t)t * H) : nullptr;
+    constexpr int MAXC = 4;   // chunks a thread keeps in registers: H <= 8 * 256 * 4 = 8192
+    half8_t r[MAXC];
+    float ss = 0.f;
+#pragma unroll
+    for (int u = 0; u < MAXC; u++) {
+        const int c = tid + u * NORM_THREADS;
+        if (c < chunks) {
+            half8_t v = xr[c];
+            if (dr) v = v + dr[c];   // fp16 add, rounded, as the residual tensors are
+            r[u] = v;
+#pragma unroll
+            for (int j = 0; j < 8; j++) ss += (float)v[j] * (float)v[j];
+        }
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) part[tid >> 6] = ss;
+    __syncthreads();
+    const float tot = part[0] + part[1] + part[2] + part[3];
+    const float rs = rsqrtf(tot / (float)H + eps);
+#pragma unroll
+    for (int u = 0; u < MAXC; u++) {
+        const int c = tid + u * NORM_THREADS;
+        if (c < chunks) {
+            const half8_t wv = reinterpret_cast<const half8_t*>(weight)[c];
+            half8_t o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float n = (float)r[u][j] * rs;     // fp32 product, then the weight: two fp32 roundings
+                o[j] = (half_t)((float)wv[j] * n);
+            }
+            reinterpret_cast<half8_t*>(y + (int64_t)t * H)[c] = o;
+            if (resid_out) reinterpret_cast<half8_t*>(resid_out + (int64_t)t * H)[c] = r[u];
+        }
+    }
+}
+
+// Rotate q and k (first half / second half pairing, every product and sum rounded to fp16), write q to q_out and
+// k, v into the paged cache at the token's slot.  qkv row = [Hq q heads][Hkv k heads][Hkv v heads] x D.
+// One workgroup per token; a work item is 8 columns of the first half of a head with their 8 partners.
+constexpr int ROPE_THREADS = 256;
+__global__ __launch_bounds__(ROPE_THREADS) void rope_kv_write_kernel(const half_t* __restrict__ qkv, const half_t* __restrict__ cos_t,
+                                                                     const half_t* __restrict__ sin_t,
+                                                                     const int32_t* __restrict__ positions,
+                                                                     const int64_t* __restrict__ slots, int Hq, int Hkv, int D,
+                                                                     int block_size, int max_pos, half_t* __restrict__ q_out,
+                                                                     half_t* __restrict__ kcache, half_t* __restrict__ vcache) {
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int half_d = D / 2, groups = half_d / 8;           // 8-column groups per half head
+    const int row_w = (Hq + 2 * Hkv) * D;
+    const half_t* row = qkv + (int64_t)t * row_w;
+    const int pos = min(max(positions[t], 0), max_pos - 1);   // the tables end at max_pos
+    const int64_t slot = slots[t];
+    const int64_t cache_row = slot >= 0 ? ((slot / block_size) * block_size + slot % block_size) * (int64_t)Hkv * D : -1;
+    const half8_t* cr = reinterpret_cast<const half8_t*>(cos_t + (int64_t)pos * half_d);
+    const half8_t* sr = reinterpret_cast<const half8_t*>(sin_t + (int64_t)pos * half_d);
+    const int rot_items = (Hq + Hkv) * groups;
+    for (int i = tid; i < rot_items; i += ROPE_THREADS) {
+        const int head = i / groups, gi = i - head * groups;
+        const half8_t a = reinterpret_cast<const half8_t*>(row + head * D)[gi];
+        const half8_t b = reinterpret_cast<const half8_t*>(row + head * D + half_d)[gi];
+        const half8_t c = cr[gi], s = sr[gi];
+        half8_t o1, o2;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+#pragma clang fp contract(off)   /* a fused multiply-add would skip the rounding of the products */
+            const half_t ac = (half_t)((float)a[j] * (float)c[j]), bs = (half_t)((float)b[j] * (float)s[j]);
+            const half_t bc = (half_t)((float)b[j] * (float)c[j]), as = (half_t)((float)a[j] * (float)s[j]);
+            o1[j] = (half_t)((float)ac - (float)bs);
+            o2[j] = (half_t)((float)bc + (float)as);
+        }
+        half_t* dst;
+        if (head < Hq) {
+            dst = q_out + ((int64_t)t * Hq + head) * D;
+        } else {
+            if (cache_row < 0) continue;
+            dst = kcache + cache_row + (head - Hq) * D;
+        }
+        reinterpret_cast<half8_t*>(dst)[gi] = o1;
+        reinterpret_cast<half8_t*>(dst + half_d)[gi] = o2;
+    }
+    if (cache_row >= 0) {
+        const int v_items = Hkv * D / 8;
+        const half8_t* vsrc = reinterpret_cast<const half8_t*>(row + (Hq + Hkv) * D);
+        for (int i = tid; i < v_items; i += ROPE_THREADS) reinterpret_cast<half8_t*>(vcache + cache_row)[i] = vsrc[i];
+    }
+}
+
+}  // namespace m355
+
+using namespace m355;
+
+extern "C" int m355_add_rmsnorm(const void* x_f16, const void* delta_f16, const void* weight_f16, float eps, int T, int H,
+                                void* resid_out_f16, void* y_f16, m355_stream_t stream) {
+    if (T == 0) return 0;
+    if (!x_f16 || !weight_f16 || !y_f16) return fail(-1, "m355_add_rmsnorm: null pointer");
+    if (T < 0 || H <= 0 || (H % 8) || H > 8 * NORM_THREADS * 4)
+        return fail(-2, "m355_add_rmsnorm: unsupported shape T=%d H=%d (need H %% 8 == 0, H <= %d)", T, H, 8 * NORM_THREADS * 4);
+    if (!aligned(x_f16, 16) || !aligned(weight_f16, 16) || !aligned(y_f16, 16) || (delta_f16 && !aligned(delta_f16, 16)) ||
+        (resid_out_f16 && !aligned(resid_out_f16, 16)))
+        return fail(-3, "m355_add_rmsnorm: buffers must be 16-byte aligned");
+    add_rmsnorm_kernel<<<dim3(T), dim3(NORM_THREADS), 0, (hipStream_t)stream>>>(
+        (const half_t*)x_f16, (const half_t*)delta_f16, (const half_t*)weight_f16, eps, H, (half_t*)resid_out_f16, (half_t*)y_f16);
+    M355_LAUNCH_CHECK("add_rmsnorm_kernel");
+    return 0;
+}
+
+extern "C" int m355_rope_kv_write(const void* qkv_f16, const void* cos_f16, const void* sin_f16, const int32_t* positions,
+                                  const int64_t* slots, int T, int Hq, int Hkv, int D, int block_size, int max_pos,
+                                  void* q_out_f16, void* kcache_f16, void* vcache_f16, m355_stream_t stream) {
+    if (T == 0) return 0;
+    if (!qkv_f16 || !cos_f16 || !sin_f16 || !positions || !slots || !q_out_f16 || !kcache_f16 || !vcache_f16)
+        return fail(-1, "m355_rope_kv_write: null pointer");
+    if (T < 0 || Hq <= 0 || Hkv <= 0 || D <= 0 || (D % 16) || block_size <= 0 || max_pos <= 0)
+        return fail(-2, "m355_rope_kv_write: unsupported shape T=%d Hq=%d Hkv=%d D=%d block_size=%d (need D %% 16 == 0)",
+                    T, Hq, Hkv, D, block_size);
+    if (!aligned(qkv_f16, 16) || !aligned(cos_f16, 16) || !aligned(sin_f16, 16) || !aligned(q_out_f16, 16) ||
+        !aligned(kcache_f16, 16) || !aligned(vcache_f16, 16))
+        return fail(-3, "m355_rope_kv_write: buffers must be 16-byte aligned");
+    rope_kv_write_kernel<<<dim3(T), dim3(ROPE_THREADS), 0, (hipStream_t)stream>>>(
+        (const half_t*)qkv_f16, (const half_t*)cos_f16, (const half_t*)sin_f16, positions, slots, Hq, Hkv, D, block_size, max_pos,
+        (half_t*)q_out_f16, (half_t*)kcache_f16, (half_t*)vcache_f16);
+    M355_LAUNCH_CHECK("rope_kv_write_kernel");
+    return 0;
+}

@@ -23,6 +23,7 @@ EXPORTS = (
     "m355_version", "m355_last_error", "m355_nf4_dequant", "m355_repack_nf4", "m355_router_topk",
     "m355_topk_softmax", "m355_moe_nf4_forward", "m355_moe_workspace_bytes", "m355_paged_attn_decode",
     "m355_paged_attn_workspace_bytes", "m355_ep_row_bytes", "m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce",
+    "m355_add_rmsnorm", "m355_rope_kv_write",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -61,8 +62,10 @@ def load() -> ctypes.CDLL:
     L.m355_ep_pack.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     L.m355_ep_unpack.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     L.m355_ep_reduce.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.m355_add_rmsnorm.argtypes = [vp, vp, vp, ctypes.c_float, i32, i32, vp, vp, vp]
+    L.m355_rope_kv_write.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     for fn in ("m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce", "m355_nf4_dequant", "m355_repack_nf4", "m355_router_topk", "m355_topk_softmax",
-               "m355_moe_nf4_forward", "m355_paged_attn_decode"):
+               "m355_moe_nf4_forward", "m355_paged_attn_decode", "m355_add_rmsnorm", "m355_rope_kv_write"):
         getattr(L, fn).restype = i32
     _lib = L
     return L
@@ -221,3 +224,37 @@ def ep_reduce(recv, n_ranks: int, T: int, H: int, out):
     _check(load().m355_ep_reduce(_dev(recv, torch.float16, "recv"), n_ranks, T, H, _dev(out, torch.float16, "out"),
                                  _stream()), "m355_ep_reduce")
     return out
+
+
+def add_rmsnorm(x: torch.Tensor, delta: Optional[torch.Tensor], weight: torch.Tensor, eps: float,
+                resid_out: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """y = rmsnorm(x + delta) * weight on fp16 rows; resid_out (optional) receives x + delta.  m355_add_rmsnorm."""
+    T, H = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _check(load().m355_add_rmsnorm(_dev(x, torch.float16, "x"), None if delta is None else _dev(delta, torch.float16, "delta"),
+                                   _dev(weight, torch.float16, "weight"), float(eps), T, H,
+                                   None if resid_out is None else _dev(resid_out, torch.float16, "resid_out"),
+                                   _dev(out, torch.float16, "out"), _stream()), "m355_add_rmsnorm")
+    return out
+
+
+def rope_kv_write(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, positions: torch.Tensor, slots: torch.Tensor,
+                  kcache: torch.Tensor, vcache: torch.Tensor, *, Hq: int, Hkv: int, D: int,
+                  q_out: Optional[torch.Tensor] = None):
+    """Rotary embedding of q and k, q to q_out [T][Hq][D], k and v into the paged cache.  m355_rope_kv_write."""
+    T = qkv.shape[0]
+    if qkv.shape[1] != (Hq + 2 * Hkv) * D:
+        raise ValueError(f"qkv rows hold {qkv.shape[1]} values, expected {(Hq + 2 * Hkv) * D}")
+    if cos.shape != sin.shape or cos.shape[1] != D // 2:
+        raise ValueError("cos/sin must be [max_pos][D/2]")
+    if kcache.shape != vcache.shape or kcache.shape[2] != Hkv or kcache.shape[3] != D:
+        raise ValueError("caches must be [blocks][block_size][Hkv][D]")
+    if q_out is None:
+        q_out = torch.empty((T, Hq, D), dtype=torch.float16, device=qkv.device)
+    _check(load().m355_rope_kv_write(_dev(qkv, torch.float16, "qkv"), _dev(cos, torch.float16, "cos"),
+                                     _dev(sin, torch.float16, "sin"), _dev(positions, torch.int32, "positions"),
+                                     _dev(slots, torch.int64, "slots"), T, Hq, Hkv, D, kcache.shape[1], cos.shape[0],
+                                     _dev(q_out, torch.float16, "q_out"), _dev(kcache, torch.float16, "kcache"),
+                                     _dev(vcache, torch.float16, "vcache"), _stream()), "m355_rope_kv_write")
+    return q_out

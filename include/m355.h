@@ -127,6 +127,27 @@ M355_API int m355_ep_unpack(const void* recv, int NT, int k, int H, void* x_all_
                             m355_stream_t stream);
 M355_API int m355_ep_reduce(const void* recv_f16, int n_ranks, int T, int H, void* out_f16, m355_stream_t stream);
 
+/*
+ * The per-token operators around the hot path in a gpt-oss decoder layer.  The reference leaves them to
+ * upstream vLLM (it patches only the MoE, the router dtype and the attention backend choice); the arithmetic
+ * here follows transformers' models/gpt_oss/modeling_gpt_oss.py operation by operation, on fp16 tensors.
+ *
+ * m355_add_rmsnorm: r = fp16(x + delta) (delta NULL: r = x); y = fp16(weight * (float(r) * rsqrt(mean(float(r)^2) +
+ *   eps))); resid_out (nullable) receives r.  GptOssRMSNorm.forward (modeling_gpt_oss.py:57-62) with the residual
+ *   add of GptOssDecoderLayer.forward in front.  x, delta, y, resid_out [T][H] fp16; weight [H] fp16; H % 8 == 0.
+ *
+ * m355_rope_kv_write: qkv [T][(Hq + 2*Hkv)*D] fp16 (q heads, k heads, v heads); cos/sin [max_pos][D/2] fp16 (YaRN
+ *   scaling already folded in, as GptOssRotaryEmbedding.forward returns them); positions [T] int32; slots [T] int64
+ *   (index of the token's row in the paged cache, block = slot / block_size; negative = do not write).  q and k are
+ *   rotated as _apply_rotary_emb does (first half / second half of a head, every product and sum rounded to fp16);
+ *   q goes to q_out [T][Hq][D], k and v into kcache / vcache [blocks][block_size][Hkv][D].  D % 16 == 0.
+ */
+M355_API int m355_add_rmsnorm(const void* x_f16, const void* delta_f16, const void* weight_f16, float eps, int T, int H,
+                              void* resid_out_f16, void* y_f16, m355_stream_t stream);
+M355_API int m355_rope_kv_write(const void* qkv_f16, const void* cos_f16, const void* sin_f16, const int32_t* positions,
+                                const int64_t* slots, int T, int Hq, int Hkv, int D, int block_size, int max_pos,
+                                void* q_out_f16, void* kcache_f16, void* vcache_f16, m355_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -189,6 +189,34 @@ def nf4_dequant_numpy(q, n_params: int, absmax_f32) -> np.ndarray:
 
 
 # ---------------------------------------------------------------------------------------------
+# Operators around the hot path (transformers models/gpt_oss/modeling_gpt_oss.py): numpy restatements
+# ---------------------------------------------------------------------------------------------
+def add_rmsnorm(x, delta, weight, eps: float):
+    """(r, y): r = fp16(x + delta) (delta None: x); y = fp16(weight * (float(r) * rsqrt(mean(float(r)^2) + eps)))
+    -- GptOssRMSNorm.forward (:57-62) behind the decoder layer's residual add."""
+    r = np.asarray(x, dtype=np.float16)
+    if delta is not None:
+        r = (r + np.asarray(delta, dtype=np.float16)).astype(np.float16)
+    rf = r.astype(np.float32)
+    var = np.mean(rf * rf, axis=-1, keepdims=True, dtype=np.float32)
+    n = rf * (np.float32(1.0) / np.sqrt(var + np.float32(eps))).astype(np.float32)
+    return r, (np.asarray(weight, dtype=np.float16).astype(np.float32) * n).astype(np.float16)
+
+
+def rope_rotate(x, cos, sin):
+    """_apply_rotary_emb (:217-225) on fp16 tensors: x [..., D], cos/sin [..., D/2] broadcastable; every product and
+    sum is rounded to fp16 as torch's half tensors round."""
+    x = np.asarray(x, dtype=np.float16)
+    h = x.shape[-1] // 2
+    a, b = x[..., :h], x[..., h:]
+    c, s = np.asarray(cos, dtype=np.float16), np.asarray(sin, dtype=np.float16)
+    m = lambda u, v: (u.astype(np.float32) * v.astype(np.float32)).astype(np.float16)
+    first = (m(a, c).astype(np.float32) - m(b, s).astype(np.float32)).astype(np.float16)
+    second = (m(b, c).astype(np.float32) + m(a, s).astype(np.float32)).astype(np.float16)
+    return np.concatenate([first, second], axis=-1)
+
+
+# ---------------------------------------------------------------------------------------------
 # bitsandbytes' own NF4 layout (the "true_bnb" loader mode).  bitsandbytes is not installed here and the
 # reference never reads a tensor this way (its loader takes the low nibble first and ignores nested_offset,
 # patches/streaming_unsloth_bnb.py:148-190), so this restates the published algorithm of bitsandbytes 0.4x

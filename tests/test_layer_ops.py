@@ -1,0 +1,110 @@
+"""Operators around the hot path (residual add + RMSNorm, rotary embedding + KV-cache write).
+
+Golden outputs come from transformers' gpt_oss modules (tests/golden/make_layer_golden.py); inputs are regenerated
+here from the same seeds.  CPU tests pin the numpy restatements and the host-side YaRN tables to those outputs; GPU
+tests pin the kernels to both.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref as oracle_ref
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+H, HQ, HKV, D = 2880, 64, 8, 64
+ROPE_POSITIONS = list(range(64)) + [255, 1000, 4095, 4096, 50000, 131071]
+TOKEN_POSITIONS = [5, 17, 4100]
+
+
+def _g(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def _norm_inputs():
+    x = oracle_ref.normal_f16(oracle_ref.stream_seed(700, 1), (5, H))
+    delta = oracle_ref.normal_f16(oracle_ref.stream_seed(700, 2), (5, H), 0.5)
+    weight = (1.0 + 0.1 * oracle_ref.normal_f16(oracle_ref.stream_seed(700, 3), (H,)).astype(np.float32)).astype(np.float16)
+    return x, delta, weight
+
+
+def _ulps(a, b):
+    return np.abs(a.view(np.int16).astype(np.int32) - b.view(np.int16).astype(np.int32)).max()
+
+
+def test_oracle_rmsnorm_vs_transformers():
+    x, delta, weight = _norm_inputs()
+    r, y = oracle_ref.add_rmsnorm(x, delta, weight, 1e-5)
+    assert np.array_equal(r.view(np.uint16), _g("layer_rmsnorm.resid.npy").view(np.uint16))
+    assert _ulps(y, _g("layer_rmsnorm.y.npy")) <= 1      # the fp32 mean is summed in a different order
+
+
+def test_host_rope_tables_vs_transformers():
+    from gpt_oss_vllm_amd import layer
+    cos, sin = layer.rope_tables(131072)
+    idx = torch.tensor(ROPE_POSITIONS)
+    assert np.array_equal(cos[idx].numpy().view(np.uint16), _g("layer_rope.cos.npy").view(np.uint16))
+    assert np.array_equal(sin[idx].numpy().view(np.uint16), _g("layer_rope.sin.npy").view(np.uint16))
+
+
+def test_oracle_rope_vs_transformers():
+    from gpt_oss_vllm_amd import layer
+    cos, sin = layer.rope_tables(4200)
+    q = oracle_ref.normal_f16(oracle_ref.stream_seed(701, 1), (3, HQ, D))
+    k = oracle_ref.normal_f16(oracle_ref.stream_seed(701, 2), (3, HKV, D))
+    c = cos[TOKEN_POSITIONS].numpy()[:, None, :]
+    s = sin[TOKEN_POSITIONS].numpy()[:, None, :]
+    assert np.array_equal(oracle_ref.rope_rotate(q, c, s).view(np.uint16), _g("layer_rope.q.npy").view(np.uint16))
+    assert np.array_equal(oracle_ref.rope_rotate(k, c, s).view(np.uint16), _g("layer_rope.k.npy").view(np.uint16))
+
+
+@pytest.mark.gpu
+def test_gpu_add_rmsnorm():
+    from gpt_oss_vllm_amd import lib
+    cuda = torch.device("cuda:0")
+    x, delta, weight = _norm_inputs()
+    xd, dd, wd = (torch.from_numpy(a).to(cuda) for a in (x, delta, weight))
+    resid = torch.empty_like(xd)
+    y = lib.add_rmsnorm(xd, dd, wd, 1e-5, resid_out=resid)
+    torch.cuda.synchronize()
+    assert np.array_equal(resid.cpu().numpy().view(np.uint16), _g("layer_rmsnorm.resid.npy").view(np.uint16))
+    assert _ulps(y.cpu().numpy(), _g("layer_rmsnorm.y.npy")) <= 1
+    # no residual: the plain norm; small and ragged row counts
+    for T, Hs in ((1, 64), (3, 8), (2, 8192)):
+        xs = oracle_ref.normal_f16(oracle_ref.stream_seed(702, T, Hs), (T, Hs))
+        ws = oracle_ref.normal_f16(oracle_ref.stream_seed(703, Hs), (Hs,))
+        got = lib.add_rmsnorm(torch.from_numpy(xs).to(cuda), None, torch.from_numpy(ws).to(cuda), 1e-6)
+        _, want = oracle_ref.add_rmsnorm(xs, None, ws, 1e-6)
+        assert _ulps(got.cpu().numpy(), want) <= 1
+    assert lib.add_rmsnorm(torch.empty((0, 64), dtype=torch.float16, device=cuda), None, wd[:64].contiguous(), 1e-5).shape == (0, 64)
+    with pytest.raises(lib.Mi355LibraryError, match="unsupported shape"):
+        lib.add_rmsnorm(torch.zeros((1, 60), dtype=torch.float16, device=cuda), None, wd[:60].contiguous(), 1e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_rope_kv_write():
+    from gpt_oss_vllm_amd import layer, lib
+    cuda = torch.device("cuda:0")
+    cos, sin = layer.rope_tables(4200)
+    T, block_size, nblocks = 3, 16, 6
+    q = oracle_ref.normal_f16(oracle_ref.stream_seed(701, 1), (T, HQ, D))
+    k = oracle_ref.normal_f16(oracle_ref.stream_seed(701, 2), (T, HKV, D))
+    v = oracle_ref.normal_f16(oracle_ref.stream_seed(701, 3), (T, HKV, D))
+    qkv = np.concatenate([q.reshape(T, -1), k.reshape(T, -1), v.reshape(T, -1)], axis=1)
+    slots = np.array([37, -1, 80], dtype=np.int64)      # the middle token is padding: its K/V must not be written
+    kc = torch.full((nblocks, block_size, HKV, D), 7.0, dtype=torch.float16, device=cuda)
+    vc = torch.full((nblocks, block_size, HKV, D), 7.0, dtype=torch.float16, device=cuda)
+    q_out = lib.rope_kv_write(torch.from_numpy(qkv).to(cuda), cos.to(cuda), sin.to(cuda),
+                              torch.tensor(TOKEN_POSITIONS, dtype=torch.int32, device=cuda), torch.from_numpy(slots).to(cuda),
+                              kc, vc, Hq=HQ, Hkv=HKV, D=D)
+    torch.cuda.synchronize()
+    assert np.array_equal(q_out.cpu().numpy().view(np.uint16), _g("layer_rope.q.npy").view(np.uint16))
+    kg = _g("layer_rope.k.npy")
+    kc_h, vc_h = kc.cpu().numpy().reshape(-1, HKV, D), vc.cpu().numpy().reshape(-1, HKV, D)
+    for t in (0, 2):
+        assert np.array_equal(kc_h[slots[t]].view(np.uint16), kg[t].view(np.uint16))
+        assert np.array_equal(vc_h[slots[t]].view(np.uint16), v[t].view(np.uint16))
+    untouched = np.ones(nblocks * block_size, dtype=bool)
+    untouched[[37, 80]] = False
+    assert (kc_h[untouched] == 7.0).all() and (vc_h[untouched] == 7.0).all()
