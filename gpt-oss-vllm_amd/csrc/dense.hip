@@ -1,0 +1,160 @@
+// Small-batch dense projection y = x W^T + b (+ residual) for decode: fp16 in, fp32 accumulate, fp16 out.
+// At <= 32 tokens the product is a stream of W through the chip once (2 bytes per weight): HBM-bound, so the kernel
+// is built like the MoE weight streamer, not like a tiled GEMM.  Tokens sit on the N side of v_mfma_f32_16x16x32_f16.
+//
+// A workgroup is 8 waves = 8 K-parts; a work item is a 16-row tile of W; a persistent workgroup walks a contiguous
+// range of row tiles.  The activations of a wave's K-part (its B fragments, <= 2 token tiles of 16) are loaded once
+// and stay in registers for the whole kernel.  The A fragments of the next item are requested as soon as the current
+// item's are consumed (register ring), a row of W being read in whole 128-byte lines (four lanes x 32 bytes).
+#include "common.h"
+
+namespace m355 {
+
+constexpr int DENSE_THREADS = 512;
+constexpr int DENSE_KPARTS = 8;
+
+__device__ __forceinline__ void dense_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// STEPS = 64-column blocks per wave and item (K <= 64 * 8 * STEPS); NT = token tiles (T <= 16 * NT).
+template <int STEPS, int NT>
+__global__ __launch_bounds__(DENSE_THREADS) void dense_stream_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
+                                                                     const half_t* __restrict__ bias,
+                                                                     const half_t* __restrict__ resid, int T, int N, int K,
+                                                                     half_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float red[2][DENSE_KPARTS - 1][NT][64][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int NB = K / 64, tiles = N / 16;
+    const int it0 = (int)((int64_t)blockIdx.x * tiles / gridDim.x), it1 = (int)((int64_t)(blockIdx.x + 1) * tiles / gridDim.x);
+    if (it0 >= it1) return;
+    const int b0 = q * NB / DENSE_KPARTS, b1 = (q + 1) * NB / DENSE_KPARTS;   // this wave's blocks
+
+    // per-lane byte offsets into a 16-row tile of W: row (lane & 15), columns 64 * block + 16 * g (+ 8)
+    uint32_t voff[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) voff[s] = (uint32_t)n * (uint32_t)K * 2u + (uint32_t)(min(b0 + s, NB - 1) * 64 + 16 * g) * 2u;
+
+    // B fragments: token (16 * tile + n, clamped), the same columns; zero where the slot is outside this wave's part
+    half8_t xb[NT][STEPS][2];
+#pragma unroll
+    for (int tt = 0; tt < NT; tt++) {
+        const int tok = min(16 * tt + n, T - 1);
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            const half8_t* src = reinterpret_cast<const half8_t*>(x + (int64_t)tok * K + min(b0 + s, NB - 1) * 64 + 16 * g);
+            const bool live = b0 + s < b1;
+            const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+            xb[tt][s][0] = live ? src[0] : z;
+            xb[tt][s][1] = live ? src[1] : z;
+        }
+    }
+
+    u32x4_t A[STEPS][2];
+    const unsigned char* wb = reinterpret_cast<const unsigned char*>(w);
+#define DENSE_LOAD(S, BASE)                                                                                       \
+    {                                                                                                             \
+        asm("" : "+v"(voff[S]));   /* keeps the offset 32-bit at the use: SGPR base + VGPR offset addressing */    \
+        A[S][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>((BASE) + voff[S]));                \
+        A[S][1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>((BASE) + voff[S] + 16));           \
+    }
+    {
+        const unsigned char* base = wb + (size_t)it0 * 16 * K * 2;
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) DENSE_LOAD(s, base)
+    }
+#define DENSE_NO_LOAD(S, BASE)
+    // One row tile.  LOAD is DENSE_LOAD while another tile follows in this workgroup's range (the ring then refills
+    // with it) and DENSE_NO_LOAD for the last one.
+#define DENSE_ITEM(IT, LOAD)                                                                                      \
+    {                                                                                                             \
+        const int it = (IT);                                                                                      \
+        const unsigned char* next = wb + (size_t)(it + 1) * 16 * K * 2;                                           \
+        (void)next;                                                                                               \
+        float4_t acc[NT];                                                                                         \
+        _Pragma("unroll") for (int tt = 0; tt < NT; tt++) acc[tt] = float4_t{0.f, 0.f, 0.f, 0.f};                 \
+        _Pragma("unroll") for (int s = 0; s < STEPS; s++) {                                                       \
+            const half8_t a0 = __builtin_bit_cast(half8_t, A[s][0]), a1 = __builtin_bit_cast(half8_t, A[s][1]);   \
+            _Pragma("unroll") for (int tt = 0; tt < NT; tt++) {                                                   \
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, xb[tt][s][0], acc[tt], 0, 0, 0);             \
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, xb[tt][s][1], acc[tt], 0, 0, 0);             \
+            }                                                                                                     \
+            LOAD(s, next)                                                                                         \
+        }                                                                                                         \
+        /* sum the K-parts through LDS (two buffers in turn: one barrier per item) */                             \
+        const int buf = round & 1;                                                                                \
+        round++;                                                                                                  \
+        if (q > 0) {                                                                                              \
+            _Pragma("unroll") for (int tt = 0; tt < NT; tt++)                                                     \
+                *reinterpret_cast<float4_t*>(red[buf][q - 1][tt][lane]) = acc[tt];                                \
+        }                                                                                                         \
+        dense_barrier();                                                                                          \
+        if (q == 0) {                                                                                             \
+            _Pragma("unroll") for (int tt = 0; tt < NT; tt++) {                                                   \
+                _Pragma("unroll") for (int qq = 0; qq < DENSE_KPARTS - 1; qq++)                                   \
+                    acc[tt] += *reinterpret_cast<const float4_t*>(red[buf][qq][tt][lane]);                        \
+                const int tok = 16 * tt + n;                                                                      \
+                if (tok < T) {                                                                                    \
+                    const int col = 16 * it + 4 * g; /* accumulator rows 4g..4g+3 of the tile = output columns */ \
+                    half4_t o;                                                                                    \
+                    const half4_t bv = bias ? *reinterpret_cast<const half4_t*>(bias + col) : half4_t{0, 0, 0, 0}; \
+                    _Pragma("unroll") for (int r = 0; r < 4; r++) o[r] = (half_t)(acc[tt][r] + (float)bv[r]);     \
+                    if (resid) o = o + *reinterpret_cast<const half4_t*>(resid + (int64_t)tok * N + col);         \
+                    *reinterpret_cast<half4_t*>(out + (int64_t)tok * N + col) = o;                                \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+    int round = 0;
+    for (int itx = it0; itx < it1 - 1; itx++) DENSE_ITEM(itx, DENSE_LOAD)
+    DENSE_ITEM(it1 - 1, DENSE_NO_LOAD)
+#undef DENSE_ITEM
+#undef DENSE_NO_LOAD
+#undef DENSE_LOAD
+}
+
+template <int STEPS, int NT>
+static int launch_dense(const half_t* x, const half_t* w, const half_t* bias, const half_t* resid, int T, int N, int K,
+                        half_t* out, int cus, hipStream_t st) {
+    const int tiles = N / 16;
+    const int grid = tiles < cus ? tiles : cus;
+    dense_stream_kernel<STEPS, NT><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, resid, T, N, K, out);
+    M355_LAUNCH_CHECK("dense_stream_kernel");
+    return 0;
+}
+
+}  // namespace m355
+
+using namespace m355;
+
+extern "C" int m355_linear_f16(const void* x_f16, int T, const void* w_f16, const void* bias_f16, int N, int K,
+                               const void* resid_f16, void* out_f16, m355_stream_t stream) {
+    if (T == 0) return 0;
+    if (!x_f16 || !w_f16 || !out_f16) return fail(-1, "m355_linear_f16: null pointer");
+    if (T < 0 || N <= 0 || K <= 0 || (N % 16) || (K % 64) || K > 64 * DENSE_KPARTS * 8)
+        return fail(-2, "m355_linear_f16: unsupported shape T=%d N=%d K=%d (need N %% 16 == 0, K %% 64 == 0, K <= %d)", T, N, K,
+                    64 * DENSE_KPARTS * 8);
+    if (!aligned(x_f16, 16) || !aligned(w_f16, 16) || !aligned(out_f16, 8) || (bias_f16 && !aligned(bias_f16, 8)) ||
+        (resid_f16 && !aligned(resid_f16, 8)))
+        return fail(-3, "m355_linear_f16: x and w must be 16-byte aligned, bias / resid / out 8-byte aligned");
+    int dev = 0, cus = 0;
+    if (int rc = hip_status(hipGetDevice(&dev), "hipGetDevice")) return rc;
+    if (int rc = hip_status(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute")) return rc;
+    if (cus <= 0) cus = 256;
+    hipStream_t st = (hipStream_t)stream;
+    const half_t *x = (const half_t*)x_f16, *w = (const half_t*)w_f16, *b = (const half_t*)bias_f16, *r = (const half_t*)resid_f16;
+    half_t* out = (half_t*)out_f16;
+    const bool small_k = K <= 64 * DENSE_KPARTS * 6;
+    // 32 tokens per pass; more tokens re-stream W once per pass (decode batches above 32 are the exception here)
+    for (int t0 = 0; t0 < T; t0 += 32) {
+        const int tn = T - t0 < 32 ? T - t0 : 32;
+        const half_t* xr = x + (int64_t)t0 * K;
+        const half_t* rr = r ? r + (int64_t)t0 * N : nullptr;
+        half_t* orow = out + (int64_t)t0 * N;
+        int rc;
+        if (tn <= 16) rc = small_k ? launch_dense<6, 1>(xr, w, b, rr, tn, N, K, orow, cus, st) : launch_dense<8, 1>(xr, w, b, rr, tn, N, K, orow, cus, st);
+        else rc = small_k ? launch_dense<6, 2>(xr, w, b, rr, tn, N, K, orow, cus, st) : launch_dense<8, 2>(xr, w, b, rr, tn, N, K, orow, cus, st);
+        if (rc) return rc;
+    }
+    return 0;
+}

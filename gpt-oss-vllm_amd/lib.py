@@ -23,7 +23,7 @@ EXPORTS = (
     "m355_version", "m355_last_error", "m355_nf4_dequant", "m355_repack_nf4", "m355_router_topk",
     "m355_topk_softmax", "m355_moe_nf4_forward", "m355_moe_workspace_bytes", "m355_paged_attn_decode",
     "m355_paged_attn_workspace_bytes", "m355_ep_row_bytes", "m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce",
-    "m355_add_rmsnorm", "m355_rope_kv_write",
+    "m355_add_rmsnorm", "m355_rope_kv_write", "m355_linear_f16",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -62,6 +62,8 @@ def load() -> ctypes.CDLL:
     L.m355_ep_pack.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     L.m355_ep_unpack.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     L.m355_ep_reduce.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.m355_linear_f16.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp, vp]
+    L.m355_linear_f16.restype = i32
     L.m355_add_rmsnorm.argtypes = [vp, vp, vp, ctypes.c_float, i32, i32, vp, vp, vp]
     L.m355_rope_kv_write.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     for fn in ("m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce", "m355_nf4_dequant", "m355_repack_nf4", "m355_router_topk", "m355_topk_softmax",
@@ -258,3 +260,19 @@ def rope_kv_write(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, posit
                                      _dev(q_out, torch.float16, "q_out"), _dev(kcache, torch.float16, "kcache"),
                                      _dev(vcache, torch.float16, "vcache"), _stream()), "m355_rope_kv_write")
     return q_out
+
+
+def linear_f16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               resid: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """out = x @ weight.T + bias (+ resid) for decode-sized x; weight in nn.Linear layout [N][K].  m355_linear_f16."""
+    T, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise ValueError(f"weight is {tuple(weight.shape)}, x has {K} columns")
+    if out is None:
+        out = torch.empty((T, N), dtype=torch.float16, device=x.device)
+    _check(load().m355_linear_f16(_dev(x, torch.float16, "x"), T, _dev(weight, torch.float16, "weight"),
+                                  None if bias is None else _dev(bias, torch.float16, "bias"), N, K,
+                                  None if resid is None else _dev(resid, torch.float16, "resid"),
+                                  _dev(out, torch.float16, "out"), _stream()), "m355_linear_f16")
+    return out

@@ -142,6 +142,14 @@ M355_API int m355_ep_reduce(const void* recv_f16, int n_ranks, int T, int H, voi
  *   rotated as _apply_rotary_emb does (first half / second half of a head, every product and sum rounded to fp16);
  *   q goes to q_out [T][Hq][D], k and v into kcache / vcache [blocks][block_size][Hkv][D].  D % 16 == 0.
  */
+/*
+ * m355_linear_f16: out[T][N] = fp16(x[T][K] . w[N][K]^T + bias[N]) (+ resid[T][N], added as an fp16 tensor add), fp32
+ *   accumulation: the q/k/v and o projections of GptOssAttention (modeling_gpt_oss.py:262-273), weights in
+ *   nn.Linear layout.  Decode-sized: W is streamed once per 32 tokens.  N % 16 == 0, K % 64 == 0, K <= 4096;
+ *   bias and resid may be NULL.
+ */
+M355_API int m355_linear_f16(const void* x_f16, int T, const void* w_f16, const void* bias_f16, int N, int K,
+                             const void* resid_f16, void* out_f16, m355_stream_t stream);
 M355_API int m355_add_rmsnorm(const void* x_f16, const void* delta_f16, const void* weight_f16, float eps, int T, int H,
                               void* resid_out_f16, void* y_f16, m355_stream_t stream);
 M355_API int m355_rope_kv_write(const void* qkv_f16, const void* cos_f16, const void* sin_f16, const int32_t* positions,

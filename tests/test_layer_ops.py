@@ -108,3 +108,29 @@ def test_gpu_rope_kv_write():
     untouched = np.ones(nblocks * block_size, dtype=bool)
     untouched[[37, 80]] = False
     assert (kc_h[untouched] == 7.0).all() and (vc_h[untouched] == 7.0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,N,K,bias,resid", [(1, 5120, 2880, True, False), (32, 2880, 4096, True, True),
+                                              (40, 64, 256, True, True), (17, 48, 64, False, False), (5, 16, 3072, False, True)])
+def test_gpu_linear_f16(T, N, K, bias, resid):
+    """q/k/v and o projection shapes of gpt-oss-20b plus ragged small ones, against an fp32 matmul of the same fp16
+    inputs (tolerance: fp16 rounding of the result plus fp32 summation order)."""
+    from gpt_oss_vllm_amd import lib
+    cuda = torch.device("cuda:0")
+    sd = oracle_ref.stream_seed(710, T, N, K)
+    x = oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 1), (T, K))
+    w = oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 2), (N, K), 0.02)
+    b = oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 3), (N,), 0.1) if bias else None
+    r = oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 4), (T, N)) if resid else None
+    want = x.astype(np.float32) @ w.astype(np.float32).T
+    if bias:
+        want = want + b.astype(np.float32)
+    want = want.astype(np.float16)
+    if resid:
+        want = (want + r).astype(np.float16)
+    dev = lambda a: None if a is None else torch.from_numpy(a).to(cuda)
+    got = lib.linear_f16(dev(x), dev(w), dev(b), dev(r))
+    torch.cuda.synchronize()
+    err = np.abs(got.cpu().numpy().astype(np.float32) - want.astype(np.float32)).max()
+    assert err <= 2e-3 * np.abs(want.astype(np.float32)).max() + 1e-5
