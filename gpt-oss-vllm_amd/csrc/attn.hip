@@ -31,7 +31,7 @@ __global__ __launch_bounds__(ATT_THREADS) void paged_attn_decode_kernel(
     const half_t* __restrict__ q, const half_t* __restrict__ kc, const half_t* __restrict__ vc,
     const int32_t* __restrict__ block_tables, const int32_t* __restrict__ ctx_lens, int Hq, int Hkv, int block_size,
     int max_blocks, float scale, int nparts, float* __restrict__ part_o, float* __restrict__ part_ml,
-    half_t* __restrict__ out) {
+    half_t* __restrict__ out, const half_t* __restrict__ sinks, int window) {
     __shared__ __attribute__((aligned(16))) float sc[ATT_PART * ATT_G];   // [token][head]
     __shared__ __attribute__((aligned(16))) float wred[4 * ATT_G * ATT_D];
     __shared__ float m_s[ATT_G], l_s[ATT_G];
@@ -41,7 +41,10 @@ __global__ __launch_bounds__(ATT_THREADS) void paged_attn_decode_kernel(
     const int ts = lane >> 3, dc = lane & 7;
     const int L = ctx_lens[b];
     const int t0 = part * ATT_PART;
-    const int npt = min(ATT_PART, L - t0);   // valid tokens in this partition (may be <= 0)
+    // sliding window: the query (position L - 1) sees keys L - window .. L - 1; tokens below `first` are masked
+    const int first = window > 0 ? max(L - window, 0) - t0 : 0;
+    int npt = min(ATT_PART, L - t0);   // tokens of this partition below the context end (may be <= 0)
+    if (first >= npt) npt = 0;         // the whole partition lies before the window
     const int64_t ob = ((int64_t)b * Hq + hk * ATT_G);
 
     if (npt <= 0) {
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(ATT_THREADS) void paged_attn_decode_kernel(
                 s = sum8(s);
                 if (dc == h) mine = s;
             }
-            sc[tl * ATT_G + dc] = (tl < npt) ? mine * scale : -INFINITY;
+            sc[tl * ATT_G + dc] = (tl < npt && tl >= first) ? mine * scale : -INFINITY;
         }
     }
     __syncthreads();
@@ -177,7 +180,14 @@ __global__ __launch_bounds__(ATT_THREADS) void paged_attn_decode_kernel(
         const float tot = wred[(0 * ATT_G + h) * ATT_D + d] + wred[(1 * ATT_G + h) * ATT_D + d] +
                           wred[(2 * ATT_G + h) * ATT_D + d] + wred[(3 * ATT_G + h) * ATT_D + d];
         if (nparts == 1) {
-            out[(ob + h) * ATT_D + d] = (half_t)(tot / l_s[h]);
+            // a sink is one more logit in the softmax denominator (its value row is dropped)
+            float num = tot, den = l_s[h];
+            if (sinks) {
+                const float sk = (float)sinks[hk * ATT_G + h], m2 = fmaxf(m_s[h], sk), f = __expf(m_s[h] - m2);
+                num *= f;
+                den = den * f + __expf(sk - m2);
+            }
+            out[(ob + h) * ATT_D + d] = (half_t)(num / den);
         } else {
             part_o[((ob + h) * nparts + part) * ATT_D + d] = tot;
             if (d == 0) {
@@ -191,12 +201,18 @@ __global__ __launch_bounds__(ATT_THREADS) void paged_attn_decode_kernel(
 // Merge the partitions of one (sequence, query head): lane = output column.
 __global__ __launch_bounds__(64) void paged_attn_merge_kernel(const float* __restrict__ part_o,
                                                               const float* __restrict__ part_ml, int nparts,
-                                                              half_t* __restrict__ out) {
+                                                              half_t* __restrict__ out, const half_t* __restrict__ sinks,
+                                                              int Hq) {
     const int64_t bh = blockIdx.x;
     const int d = threadIdx.x;
     float mx = -INFINITY;
     for (int p = 0; p < nparts; p++) mx = fmaxf(mx, part_ml[(bh * nparts + p) * 2]);
     float num = 0.f, den = 0.f;
+    if (sinks) {
+        const float sk = (float)sinks[bh % Hq];
+        mx = fmaxf(mx, sk);
+        den = __expf(sk - mx);
+    }
     for (int p = 0; p < nparts; p++) {
         const float m = part_ml[(bh * nparts + p) * 2], l = part_ml[(bh * nparts + p) * 2 + 1];
         if (l <= 0.f) continue;
@@ -221,7 +237,17 @@ extern "C" int m355_paged_attn_decode(const void* q_f16, const void* kcache_f16,
                                       const int32_t* block_tables, const int32_t* ctx_lens, int B, int Hq, int Hkv, int D,
                                       int block_size, int max_blocks, int max_ctx, float scale, void* workspace,
                                       size_t ws_bytes, void* out_f16, m355_stream_t stream) {
+    return m355_paged_attn_decode_ex(q_f16, kcache_f16, vcache_f16, block_tables, ctx_lens, B, Hq, Hkv, D, block_size,
+                                     max_blocks, max_ctx, scale, nullptr, 0, workspace, ws_bytes, out_f16, stream);
+}
+
+extern "C" int m355_paged_attn_decode_ex(const void* q_f16, const void* kcache_f16, const void* vcache_f16,
+                                         const int32_t* block_tables, const int32_t* ctx_lens, int B, int Hq, int Hkv, int D,
+                                         int block_size, int max_blocks, int max_ctx, float scale, const void* sinks_f16,
+                                         int window, void* workspace, size_t ws_bytes, void* out_f16,
+                                         m355_stream_t stream) {
     if (B == 0) return 0;
+    if (window < 0) return fail(-2, "m355_paged_attn_decode: negative window %d", window);
     if (!q_f16 || !kcache_f16 || !vcache_f16 || !block_tables || !ctx_lens || !out_f16)
         return fail(-1, "m355_paged_attn_decode: null pointer");
     if (B < 0 || Hkv <= 0 || Hq != Hkv * ATT_G || D != ATT_D || block_size <= 0 || max_blocks <= 0 || max_ctx <= 0)
@@ -243,10 +269,10 @@ extern "C" int m355_paged_attn_decode(const void* q_f16, const void* kcache_f16,
     hipStream_t st = (hipStream_t)stream;
     paged_attn_decode_kernel<<<dim3(B, Hkv, nparts), dim3(ATT_THREADS), 0, st>>>(
         (const half_t*)q_f16, (const half_t*)kcache_f16, (const half_t*)vcache_f16, block_tables, ctx_lens, Hq, Hkv,
-        block_size, max_blocks, scale, nparts, po, pml, (half_t*)out_f16);
+        block_size, max_blocks, scale, nparts, po, pml, (half_t*)out_f16, (const half_t*)sinks_f16, window);
     M355_LAUNCH_CHECK("paged_attn_decode_kernel");
     if (nparts > 1) {
-        paged_attn_merge_kernel<<<dim3(B * Hq), dim3(64), 0, st>>>(po, pml, nparts, (half_t*)out_f16);
+        paged_attn_merge_kernel<<<dim3(B * Hq), dim3(64), 0, st>>>(po, pml, nparts, (half_t*)out_f16, (const half_t*)sinks_f16, Hq);
         M355_LAUNCH_CHECK("paged_attn_merge_kernel");
     }
     return 0;

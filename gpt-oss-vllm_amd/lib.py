@@ -23,7 +23,7 @@ EXPORTS = (
     "m355_version", "m355_last_error", "m355_nf4_dequant", "m355_repack_nf4", "m355_router_topk",
     "m355_topk_softmax", "m355_moe_nf4_forward", "m355_moe_workspace_bytes", "m355_paged_attn_decode",
     "m355_paged_attn_workspace_bytes", "m355_ep_row_bytes", "m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce",
-    "m355_add_rmsnorm", "m355_rope_kv_write", "m355_linear_f16",
+    "m355_add_rmsnorm", "m355_rope_kv_write", "m355_linear_f16", "m355_paged_attn_decode_ex",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -55,6 +55,8 @@ def load() -> ctypes.CDLL:
     L.m355_moe_workspace_bytes.argtypes = [i32, i32, i32, i32, i32]
     L.m355_moe_workspace_bytes.restype = sz
     L.m355_paged_attn_decode.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, sz, vp, vp]
+    L.m355_paged_attn_decode_ex.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, i32, vp, sz, vp, vp]
+    L.m355_paged_attn_decode_ex.restype = i32
     L.m355_paged_attn_workspace_bytes.argtypes = [i32, i32, i32, i32]
     L.m355_paged_attn_workspace_bytes.restype = sz
     L.m355_ep_row_bytes.argtypes = [i32, i32]
@@ -175,8 +177,10 @@ def paged_attn_workspace_bytes(B: int, Hq: int, D: int, max_ctx: int) -> int:
 
 
 def paged_attn_decode(q, kcache, vcache, block_tables, ctx_lens, *, max_ctx: int, scale: float,
-                      workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
-    """Decode attention over a paged KV cache.  m355_paged_attn_decode."""
+                      workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                      sinks: Optional[torch.Tensor] = None, window: int = 0):
+    """Decode attention over a paged KV cache; sinks [Hq] fp16 and a sliding window are optional.
+    m355_paged_attn_decode_ex."""
     B, Hq, D = q.shape
     _, block_size, Hkv, _ = kcache.shape
     need = paged_attn_workspace_bytes(B, Hq, D, max_ctx)
@@ -184,10 +188,13 @@ def paged_attn_decode(q, kcache, vcache, block_tables, ctx_lens, *, max_ctx: int
         workspace = torch.empty(need, dtype=torch.uint8, device=q.device)
     if out is None:
         out = torch.empty_like(q)
-    _check(load().m355_paged_attn_decode(
+    if sinks is not None and sinks.numel() != Hq:
+        raise ValueError(f"sinks has {sinks.numel()} entries, expected one per query head ({Hq})")
+    _check(load().m355_paged_attn_decode_ex(
         _dev(q, torch.float16, "q"), _dev(kcache, torch.float16, "kcache"), _dev(vcache, torch.float16, "vcache"),
         _dev(block_tables, torch.int32, "block_tables"), _dev(ctx_lens, torch.int32, "ctx_lens"), B, Hq, Hkv, D,
         block_size, block_tables.shape[1], max_ctx, scale,
+        None if sinks is None else _dev(sinks, torch.float16, "sinks"), int(window),
         None if workspace is None else _dev(workspace, torch.uint8, "workspace"),
         0 if workspace is None else workspace.numel(), _dev(out, torch.float16, "out"), _stream()),
         "m355_paged_attn_decode")

@@ -110,6 +110,16 @@ M355_API int m355_paged_attn_decode(const void* q_f16, const void* kcache_f16, c
                                     int D, int block_size, int max_blocks, int max_ctx, float scale,
                                     void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream);
 M355_API size_t m355_paged_attn_workspace_bytes(int B, int Hq, int D, int max_ctx);
+/*
+ * The same with gpt-oss's two attention extras, which the reference switches off because its GPU's FA2 lacks them
+ * (patches/patch_3_disable_sinks.py:29-40): sinks_f16 [Hq] (nullable) is one extra logit per query head in the
+ * softmax denominator (eager_attention_forward, transformers models/gpt_oss/modeling_gpt_oss.py:243-251); window > 0
+ * limits a query to the last `window` cached tokens (config.sliding_window on "sliding_attention" layers), 0 = all.
+ */
+M355_API int m355_paged_attn_decode_ex(const void* q_f16, const void* kcache_f16, const void* vcache_f16,
+                                       const int32_t* block_tables, const int32_t* ctx_lens, int B, int Hq, int Hkv, int D,
+                                       int block_size, int max_blocks, int max_ctx, float scale, const void* sinks_f16,
+                                       int window, void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream);
 
 /*
  * Expert-parallel exchange helpers.  No counterpart in the reference (it is single-GPU, tensor_parallel_size=1:

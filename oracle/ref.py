@@ -159,6 +159,32 @@ def paged_attn_decode(q, kcache, vcache, block_tables, ctx_lens, scale: float) -
     return out
 
 
+def paged_attn_decode_ex(q, kcache, vcache, block_tables, ctx_lens, scale: float, sinks=None, window: int = 0) -> np.ndarray:
+    """Decode attention with gpt-oss's extras, in fp32 numpy: a sink logit per query head joins the softmax
+    denominator and is then dropped (eager_attention_forward, transformers models/gpt_oss/modeling_gpt_oss.py:243-251);
+    window > 0 keeps the last `window` cached tokens.  fp16 in / fp16 out like the C function above."""
+    q = np.asarray(q, dtype=np.float16)
+    B, Hq, D = q.shape
+    _, block_size, Hkv, _ = kcache.shape
+    G = Hq // Hkv
+    out = np.zeros_like(q)
+    for b in range(B):
+        L = int(ctx_lens[b])
+        lo = max(L - window, 0) if window > 0 else 0
+        if L <= lo:
+            continue
+        rows = [int(block_tables[b, t // block_size]) * block_size + t % block_size for t in range(lo, L)]
+        K = np.asarray(kcache, dtype=np.float16).reshape(-1, Hkv, D)[rows].astype(np.float32)
+        V = np.asarray(vcache, dtype=np.float16).reshape(-1, Hkv, D)[rows].astype(np.float32)
+        for h in range(Hq):
+            s = (K[:, h // G, :] @ q[b, h].astype(np.float32)) * np.float32(scale)
+            logits = s if sinks is None else np.concatenate([s, [np.float32(sinks[h])]])
+            p = np.exp(logits - logits.max())
+            p = p / p.sum()
+            out[b, h] = (p[:len(s)] @ V[:, h // G, :]).astype(np.float16)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # numpy twin of the dequantizer (cross-checks the C code; same reference lines)
 # ---------------------------------------------------------------------------------------------

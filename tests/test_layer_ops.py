@@ -134,3 +134,65 @@ def test_gpu_linear_f16(T, N, K, bias, resid):
     torch.cuda.synchronize()
     err = np.abs(got.cpu().numpy().astype(np.float32) - want.astype(np.float32)).max()
     assert err <= 2e-3 * np.abs(want.astype(np.float32)).max() + 1e-5
+
+
+ATTN_CASES = (("sinks_full", 300, 0), ("sinks_window", 300, 128), ("sinks_short", 70, 128))
+
+
+def _attn_case(ctx, window):
+    sd = oracle_ref.stream_seed(705, ctx, window)
+    q = oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 1), (1, HQ, D))
+    k = oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 2), (ctx, HKV, D))
+    v = oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 3), (ctx, HKV, D))
+    sinks = oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 4), (HQ,), 2.0)
+    block_size = 16
+    nblk = (ctx + block_size - 1) // block_size
+    perm = np.random.default_rng(ctx).permutation(nblk).astype(np.int32)     # scattered pages
+    kc = np.zeros((nblk, block_size, HKV, D), np.float16)
+    vc = np.zeros((nblk, block_size, HKV, D), np.float16)
+    for t in range(ctx):
+        kc[perm[t // block_size], t % block_size] = k[t]
+        vc[perm[t // block_size], t % block_size] = v[t]
+    return q, kc, vc, perm[None, :].copy(), np.array([ctx], np.int32), sinks
+
+
+@pytest.mark.parametrize("name,ctx,window", ATTN_CASES)
+def test_oracle_attention_sinks_window_vs_transformers(name, ctx, window):
+    q, kc, vc, bt, cl, sinks = _attn_case(ctx, window)
+    got = oracle_ref.paged_attn_decode_ex(q, kc, vc, bt, cl, D ** -0.5, sinks=sinks, window=window)
+    want = _g(f"layer_attn.{name}.npy")
+    assert np.abs(got[0].astype(np.float32) - want).max() <= 2e-3 * np.abs(want).max() + 1e-5
+    # without extras the numpy function is the C oracle's attention
+    plain = oracle_ref.paged_attn_decode_ex(q, kc, vc, bt, cl, D ** -0.5)
+    base = oracle_ref.paged_attn_decode(q, kc, vc, bt, cl, D ** -0.5)
+    assert np.abs(plain.astype(np.float32) - base.astype(np.float32)).max() <= 2e-3 * np.abs(base.astype(np.float32)).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,ctx,window", ATTN_CASES)
+def test_gpu_attention_sinks_window(name, ctx, window):
+    from gpt_oss_vllm_amd import lib
+    cuda = torch.device("cuda:0")
+    q, kc, vc, bt, cl, sinks = _attn_case(ctx, window)
+    dev = lambda a: torch.from_numpy(a).to(cuda)
+    out = lib.paged_attn_decode(dev(q), dev(kc), dev(vc), dev(bt), dev(cl), max_ctx=ctx, scale=D ** -0.5,
+                                sinks=dev(sinks), window=window)
+    torch.cuda.synchronize()
+    want = _g(f"layer_attn.{name}.npy")
+    assert np.abs(out.cpu().numpy()[0].astype(np.float32) - want).max() <= 2e-3 * np.abs(want).max() + 1e-5
+    # window without sinks, and a batch whose sequences sit on both sides of the window and of the partition size
+    ctxs = [300, 5, 129, 600]
+    B = len(ctxs)
+    nblk_seq = (max(ctxs) + 15) // 16
+    rng = np.random.default_rng(9)
+    kcb = oracle_ref.normal_f16(oracle_ref.stream_seed(706, 1), (B * nblk_seq, 16, HKV, D))
+    vcb = oracle_ref.normal_f16(oracle_ref.stream_seed(706, 2), (B * nblk_seq, 16, HKV, D))
+    btb = rng.permutation(B * nblk_seq).astype(np.int32).reshape(B, nblk_seq)
+    qb = oracle_ref.normal_f16(oracle_ref.stream_seed(706, 3), (B, HQ, D))
+    clb = np.array(ctxs, np.int32)
+    for sk in (None, sinks):
+        got = lib.paged_attn_decode(dev(qb), dev(kcb), dev(vcb), dev(btb), dev(clb), max_ctx=max(ctxs), scale=D ** -0.5,
+                                    sinks=None if sk is None else dev(sk), window=128)
+        exp = oracle_ref.paged_attn_decode_ex(qb, kcb, vcb, btb, clb, D ** -0.5, sinks=sk, window=128)
+        torch.cuda.synchronize()
+        assert np.abs(got.cpu().numpy().astype(np.float32) - exp.astype(np.float32)).max() <= 2e-3 * np.abs(exp.astype(np.float32)).max() + 1e-5
