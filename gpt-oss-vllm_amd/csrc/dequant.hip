@@ -47,8 +47,15 @@ __global__ __launch_bounds__(256) void nf4_dequant_kernel(const uint32_t* __rest
     }
 }
 
+// Row of the checkpoint matrix that becomes row `row` of the kernels' order: as is, or (row_order 1) the even
+// checkpoint rows first, then the odd ones -- gate/up interleaved in the checkpoint, gate rows then up rows here.
+__device__ __forceinline__ int source_row(int row, int rows, int row_order) {
+    if (row_order == 0) return row;
+    return row < rows / 2 ? 2 * row : 2 * (row - rows / 2) + 1;
+}
+
 // One thread per 8-byte granule of the tiled image.
-__global__ __launch_bounds__(256) void repack_q_kernel(const uint2* __restrict__ q, int rows, int cols,
+__global__ __launch_bounds__(256) void repack_q_kernel(const uint2* __restrict__ q, int rows, int cols, int row_order,
                                                        uint2* __restrict__ qt) {
     const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)rows * cols / 16;
@@ -59,12 +66,12 @@ __global__ __launch_bounds__(256) void repack_q_kernel(const uint2* __restrict__
     const int64_t pb = o >> 7;
     const int b = (int)(pb % NB), p = (int)(pb / NB);
     const int r = lane & 15, g = lane >> 4;
-    const int row = 16 * (p + half * P) + r;
+    const int row = source_row(16 * (p + half * P) + r, rows, row_order);
     const int64_t src_byte = ((int64_t)row * cols + 64 * b + 16 * g) / 2;
     qt[o] = q[src_byte / 8];
 }
 
-__global__ __launch_bounds__(256) void repack_absmax_kernel(const float* __restrict__ a, int rows, int cols,
+__global__ __launch_bounds__(256) void repack_absmax_kernel(const float* __restrict__ a, int rows, int cols, int row_order,
                                                             float* __restrict__ at) {
     const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int NB = cols / 64, P = rows / 32;
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(256) void repack_absmax_kernel(const float* __restr
     t >>= 2;
     const int half = (int)(t & 1);
     const int p = (int)(t >> 1);
-    const int row = 16 * (p + half * P) + 4 * g + i;
+    const int row = source_row(16 * (p + half * P) + 4 * g + i, rows, row_order);
     at[o] = a[(int64_t)row * NB + b];
 }
 
@@ -104,6 +111,12 @@ extern "C" int m355_nf4_dequant(const uint8_t* q, const float* absmax, int64_t n
 
 extern "C" int m355_repack_nf4(const uint8_t* q, const float* absmax, int rows, int cols, uint8_t* q_tiled,
                                float* absmax_tiled, m355_stream_t stream) {
+    return m355_repack_nf4_ex(q, absmax, rows, cols, 0, q_tiled, absmax_tiled, stream);
+}
+
+extern "C" int m355_repack_nf4_ex(const uint8_t* q, const float* absmax, int rows, int cols, int row_order,
+                                  uint8_t* q_tiled, float* absmax_tiled, m355_stream_t stream) {
+    if (row_order != 0 && row_order != 1) return fail(-2, "m355_repack_nf4: row_order %d (0 = as is, 1 = interleaved pairs)", row_order);
     if (!q || !absmax || !q_tiled || !absmax_tiled) return fail(-1, "m355_repack_nf4: null pointer");
     if (rows <= 0 || cols <= 0 || (rows % 32) || (cols % 64))
         return fail(-2, "m355_repack_nf4: need rows %% 32 == 0 and cols %% 64 == 0 (rows=%d, cols=%d)", rows, cols);
@@ -111,10 +124,10 @@ extern "C" int m355_repack_nf4(const uint8_t* q, const float* absmax, int rows, 
     if (q == q_tiled || absmax == absmax_tiled) return fail(-4, "m355_repack_nf4: in-place repack is not supported");
     const int64_t granules = (int64_t)rows * cols / 16;
     repack_q_kernel<<<dim3((unsigned)((granules + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(
-        reinterpret_cast<const uint2*>(q), rows, cols, reinterpret_cast<uint2*>(q_tiled));
+        reinterpret_cast<const uint2*>(q), rows, cols, row_order, reinterpret_cast<uint2*>(q_tiled));
     M355_LAUNCH_CHECK("m355_repack_nf4(q)");
     const int64_t na = (int64_t)rows * (cols / 64);
-    repack_absmax_kernel<<<dim3((unsigned)((na + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(absmax, rows, cols,
+    repack_absmax_kernel<<<dim3((unsigned)((na + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(absmax, rows, cols, row_order,
                                                                                                    absmax_tiled);
     M355_LAUNCH_CHECK("m355_repack_nf4(absmax)");
     return 0;

@@ -357,18 +357,42 @@ __global__ __launch_bounds__(MOE_THREADS) void moe_gemm_kernel(const half_t* __r
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Write one lane's 4 rows of both tiles for token row `orow`: h = silu(gate) * up (MODE 0) or the raw y (MODE 1).
+// Activation and bias of one GEMM stage.  bias: [E_local][R] fp16 in the kernel's row order (gate rows, then up rows),
+// or null.
+struct StageParams {
+    int act_mode;            // M355_ACT_* (gate_up stage only)
+    float alpha, limit;      // swiglu-oai
+    const half_t* bias;
+};
+
+// Write one lane's 4 rows of both tiles for token row `orow`: h = act(gate, up) (MODE 0) or y (MODE 1), expert e.
 template <int MODE>
-__device__ __forceinline__ void gemm_epilogue(const float4_t& accA, const float4_t& accB, half_t* __restrict__ outp,
-                                              int64_t orow, int R, int NP, int p, int g) {
+__device__ __forceinline__ void gemm_epilogue(float4_t accA, float4_t accB, half_t* __restrict__ outp,
+                                              int64_t orow, int R, int NP, int p, int g, int e, const StageParams& sp) {
+    if (sp.bias) {   // rows 16p + 4g .. +3 of the first tile, the same rows of the partner tile
+        const half4_t ba = *reinterpret_cast<const half4_t*>(sp.bias + (int64_t)e * R + 16 * p + 4 * g);
+        const half4_t bb = *reinterpret_cast<const half4_t*>(sp.bias + (int64_t)e * R + 16 * (p + NP) + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; r++) { accA[r] += (float)ba[r]; accB[r] += (float)bb[r]; }
+    }
     if (MODE == 0) {
         half4_t hv;
+        if (sp.act_mode == M355_ACT_SWIGLU_OAI) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float gt = (float)(half_t)accA[r];   // gate and up leave the GEMM as fp16
-            const float up = (float)(half_t)accB[r];
-            const half_t sg = (half_t)(gt / (1.0f + expf(-gt)));
-            hv[r] = (half_t)((float)sg * up);
+            for (int r = 0; r < 4; r++) {
+                const float gt = fminf((float)(half_t)accA[r], sp.limit);   // gate and up leave the GEMM as fp16
+                const float up = fminf(fmaxf((float)(half_t)accB[r], -sp.limit), sp.limit);
+                const float glu = gt / (1.0f + expf(-sp.alpha * gt));
+                hv[r] = (half_t)((up + 1.0f) * glu);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float gt = (float)(half_t)accA[r];   // gate and up leave the GEMM as fp16
+                const float up = (float)(half_t)accB[r];
+                const half_t sg = (half_t)(gt / (1.0f + expf(-gt)));
+                hv[r] = (half_t)((float)sg * up);
+            }
         }
         *reinterpret_cast<half4_t*>(outp + orow * (R / 2) + 16 * p + 4 * g) = hv;
     } else {
@@ -495,7 +519,7 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     const half_t* __restrict__ xin, const uint8_t* __restrict__ wq, const float* __restrict__ wam,
     const int32_t* __restrict__ n_tiles, const int32_t* __restrict__ tile_expert, const int32_t* __restrict__ tile_m0,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ sorted, int K, int R, int k_top, int mt_rows,
-    half_t* __restrict__ outp, int table_len, RouteIO rio) {
+    half_t* __restrict__ outp, int table_len, RouteIO rio, StageParams sp) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int THREADS = PAIRS * 256;
     constexpr int RED_ALL = 2 * PAIRS * (MOE_KPARTS - 1) * 64 * 8 * 4;   // both reduction buffers
@@ -695,7 +719,7 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
                 accA += src[0];                                                                             \
                 accB += src[1];                                                                             \
             }                                                                                               \
-            if (n < mt) gemm_epilogue<MODE>(accA, accB, outp, pos0 + n, R, NP, p, g);                       \
+            if (n < mt) gemm_epilogue<MODE>(accA, accB, outp, pos0 + n, R, NP, p, g, e, sp);                \
         }                                                                                                   \
     }
 
@@ -800,7 +824,8 @@ static bool can_route_inline(int P, int E_local, int K) {
 // `rio` non-null (gate_up only): the kernel buckets the pairs itself and leaves the lists in the workspace.
 template <int MODE, bool INLINE>
 static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, const MoeWorkspace& ws, int K, int R,
-                       int k_top, int mt_rows, int slots, half_t* outp, int cus, hipStream_t st, const RouteIO& rio) {
+                       int k_top, int mt_rows, int slots, half_t* outp, int cus, hipStream_t st, const RouteIO& rio,
+                       const StageParams& sp) {
     const int NP = R / 32, NB = K / 64;
     if (NB <= MOE_KPARTS * MOE_CHUNK) {
         // upper bound of sum_e ceil(M_e / mt_rows): with T <= 16 a token tile holds a whole expert (M_e <= T = mt_rows)
@@ -811,18 +836,20 @@ static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, c
             const int lds = stream_lds_bytes(2, INLINE);
             const int grid = items2 < cus ? items2 : cus;
             moe_gemm_stream_kernel<MODE, 2, INLINE><<<dim3(grid), dim3(512), lds, st>>>(
-                xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio);
+                xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio, sp);
         } else {
             const int lds = stream_lds_bytes(1, INLINE);
             const int per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
             const int items1 = max_tiles * NP;
             const int grid = items1 < per_cu * cus ? items1 : per_cu * cus;
             moe_gemm_stream_kernel<MODE, 1, INLINE><<<dim3(grid), dim3(256), lds, st>>>(
-                xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio);
+                xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio, sp);
         }
         M355_LAUNCH_CHECK("moe_gemm_stream_kernel");
         return 0;
     }
+    if (sp.bias || sp.act_mode != M355_ACT_SILU_CONCAT)
+        return fail(-5, "m355_moe_nf4_forward: biases and swiglu-oai need K <= %d (K = %d)", 64 * MOE_KPARTS * MOE_CHUNK, K);
     moe_gemm_kernel<MODE><<<dim3((NP + MOE_PAIRS - 1) / MOE_PAIRS, slots), dim3(MOE_THREADS), gemm_lds_bytes(K, mt_rows), st>>>(
         xin, wq, wam, ws.n_active, ws.offsets, ws.active, ws.sorted, K, R, k_top, mt_rows, outp);
     M355_LAUNCH_CHECK("moe_gemm_kernel");
@@ -842,13 +869,27 @@ extern "C" int m355_moe_nf4_forward(const void* x_f16, int T, const int32_t* ids
                                     const uint8_t* w13_q, const float* w13_absmax, const uint8_t* w2_q,
                                     const float* w2_absmax, int E_local, int e_first, int H, int FF, int act_mode,
                                     int flags, void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream) {
+    return m355_moe_nf4_forward_ex(x_f16, T, ids, w, k, w13_q, w13_absmax, w2_q, w2_absmax, E_local, e_first, H, FF, act_mode,
+                                   flags, nullptr, nullptr, 1.702f, 7.0f, workspace, ws_bytes, out_f16, stream);
+}
+
+extern "C" int m355_moe_nf4_forward_ex(const void* x_f16, int T, const int32_t* ids, const float* w, int k,
+                                       const uint8_t* w13_q, const float* w13_absmax, const uint8_t* w2_q,
+                                       const float* w2_absmax, int E_local, int e_first, int H, int FF, int act_mode,
+                                       int flags, const void* b13_f16, const void* b2_f16, float alpha, float limit,
+                                       void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream) {
     if (T == 0) return 0;   // an empty batch has no buffers to check
     if (!x_f16 || !ids || !w || !w13_q || !w13_absmax || !w2_q || !w2_absmax || !out_f16)
         return fail(-1, "m355_moe_nf4_forward: null pointer");
     if (T < 0 || k <= 0 || k > 32 || E_local <= 0 || E_local > ROUTE_MAX_E || H <= 0 || FF <= 0 || (H % 64) || (FF % 64))
         return fail(-2, "m355_moe_nf4_forward: unsupported shape T=%d k=%d E_local=%d H=%d FF=%d (need H,FF %% 64 == 0, k <= 32, E_local <= %d)",
                     T, k, E_local, H, FF, ROUTE_MAX_E);
-    if (act_mode != M355_ACT_SILU_CONCAT) return fail(-5, "m355_moe_nf4_forward: act_mode %d not supported", act_mode);
+    if (act_mode != M355_ACT_SILU_CONCAT && act_mode != M355_ACT_SWIGLU_OAI)
+        return fail(-5, "m355_moe_nf4_forward: act_mode %d not supported", act_mode);
+    if ((b13_f16 && !aligned(b13_f16, 8)) || (b2_f16 && !aligned(b2_f16, 8)))
+        return fail(-3, "m355_moe_nf4_forward: biases must be 8-byte aligned");
+    const StageParams sp13 = {act_mode, alpha, limit, (const half_t*)b13_f16};
+    const StageParams sp2 = {M355_ACT_SILU_CONCAT, 0.f, 0.f, (const half_t*)b2_f16};
     if ((int64_t)T * k > (int64_t)1 << 24) return fail(-2, "m355_moe_nf4_forward: T*k too large");
     const size_t need = m355_moe_workspace_bytes(T, k, H, FF, E_local);
     if (!workspace || ws_bytes < need) return fail(-6, "m355_moe_nf4_forward: workspace of %zu bytes needed, %zu given", need, ws_bytes);
@@ -877,12 +918,12 @@ extern "C" int m355_moe_nf4_forward(const void* x_f16, int T, const int32_t* ids
         M355_LAUNCH_CHECK("moe_route_kernel");
     }
     if (!(flags & M355_FLAG_SKIP_GATE_UP)) {
-        if (int rc = inline_route ? launch_gemm<0, true>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio)
-                                  : launch_gemm<0, false>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio))
+        if (int rc = inline_route ? launch_gemm<0, true>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13)
+                                  : launch_gemm<0, false>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13))
             return rc;
     }
     if (!(flags & M355_FLAG_SKIP_DOWN)) {
-        if (int rc = launch_gemm<1, false>(ws.h, w2_q, w2_absmax, ws, FF, H, k, mt_rows, slots, ws.y, cus, st, rio)) return rc;
+        if (int rc = launch_gemm<1, false>(ws.h, w2_q, w2_absmax, ws, FF, H, k, mt_rows, slots, ws.y, cus, st, rio, sp2)) return rc;
     }
     if (!(flags & M355_FLAG_SKIP_COMBINE)) {
         moe_combine_kernel<<<dim3(T), dim3(256), 0, st>>>(ws.y, ws.inv, w, H, k, (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0,

@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("M355_LIB_PATH") or os.path.join(_HERE, "libmoe355.so")
 
 ACT_SILU_CONCAT = 0
+ACT_SWIGLU_OAI = 1
 FLAG_FP16_COMBINE = 1
 FLAG_SKIP_ROUTE, FLAG_SKIP_GATE_UP, FLAG_SKIP_DOWN, FLAG_SKIP_COMBINE = 0x100, 0x200, 0x400, 0x800
 
@@ -24,6 +25,7 @@ EXPORTS = (
     "m355_topk_softmax", "m355_moe_nf4_forward", "m355_moe_workspace_bytes", "m355_paged_attn_decode",
     "m355_paged_attn_workspace_bytes", "m355_ep_row_bytes", "m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce",
     "m355_add_rmsnorm", "m355_rope_kv_write", "m355_linear_f16", "m355_paged_attn_decode_ex",
+    "m355_repack_nf4_ex", "m355_moe_nf4_forward_ex",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -48,6 +50,11 @@ def load() -> ctypes.CDLL:
     L.m355_last_error.restype = ctypes.c_char_p
     L.m355_nf4_dequant.argtypes = [vp, vp, i64, i32, vp, vp]
     L.m355_repack_nf4.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    L.m355_repack_nf4_ex.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    L.m355_repack_nf4_ex.restype = i32
+    L.m355_moe_nf4_forward_ex.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
+                                          vp, vp, f32, f32, vp, sz, vp, vp]
+    L.m355_moe_nf4_forward_ex.restype = i32
     L.m355_router_topk.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     L.m355_topk_softmax.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     L.m355_moe_nf4_forward.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
@@ -110,15 +117,16 @@ def nf4_dequant(q: torch.Tensor, absmax: torch.Tensor, blocksize: int = 64, out:
     return out
 
 
-def repack_nf4(q: torch.Tensor, absmax: torch.Tensor, rows: int, cols: int):
-    """One expert matrix, checkpoint order -> tile order.  m355_repack_nf4."""
+def repack_nf4(q: torch.Tensor, absmax: torch.Tensor, rows: int, cols: int, row_order: int = 0):
+    """One expert matrix, checkpoint order -> tile order; row_order 1 = gate/up rows interleaved in the
+    checkpoint.  m355_repack_nf4_ex."""
     if q.numel() * 2 != rows * cols or absmax.numel() * 64 != rows * cols:
         raise ValueError("repack_nf4: sizes do not match rows*cols")
     qt = torch.empty_like(q)
     at = torch.empty_like(absmax)
-    _check(load().m355_repack_nf4(_dev(q, torch.uint8, "q"), _dev(absmax, torch.float32, "absmax"), rows, cols,
-                                  _dev(qt, torch.uint8, "q_tiled"), _dev(at, torch.float32, "absmax_tiled"), _stream()),
-           "m355_repack_nf4")
+    _check(load().m355_repack_nf4_ex(_dev(q, torch.uint8, "q"), _dev(absmax, torch.float32, "absmax"), rows, cols,
+                                     int(row_order), _dev(qt, torch.uint8, "q_tiled"),
+                                     _dev(at, torch.float32, "absmax_tiled"), _stream()), "m355_repack_nf4")
     return qt, at
 
 
@@ -155,19 +163,28 @@ def moe_workspace_bytes(T: int, k: int, H: int, FF: int, E_local: int) -> int:
 
 def moe_nf4_forward(x, ids, w, w13_q, w13_absmax, w2_q, w2_absmax, *, E_local: int, e_first: int, H: int, FF: int,
                     workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                    act_mode: int = ACT_SILU_CONCAT, flags: int = FLAG_FP16_COMBINE):
-    """One MoE layer over this rank's experts (weights in tile order).  m355_moe_nf4_forward."""
+                    act_mode: int = ACT_SILU_CONCAT, flags: int = FLAG_FP16_COMBINE,
+                    b13: Optional[torch.Tensor] = None, b2: Optional[torch.Tensor] = None, alpha: float = 1.702,
+                    limit: float = 7.0):
+    """One MoE layer over this rank's experts (weights in tile order); optional per-expert biases b13 [E][2FF]
+    (gate entries then up entries), b2 [E][H].  m355_moe_nf4_forward_ex."""
     T, k = ids.shape
     need = moe_workspace_bytes(T, k, H, FF, E_local)
     if workspace is None:
         workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=x.device)
     if out is None:
         out = torch.empty((T, H), dtype=torch.float16, device=x.device)
-    _check(load().m355_moe_nf4_forward(
+    if b13 is not None and tuple(b13.shape) != (E_local, 2 * FF):
+        raise ValueError(f"b13 is {tuple(b13.shape)}, expected {(E_local, 2 * FF)}")
+    if b2 is not None and tuple(b2.shape) != (E_local, H):
+        raise ValueError(f"b2 is {tuple(b2.shape)}, expected {(E_local, H)}")
+    _check(load().m355_moe_nf4_forward_ex(
         _dev(x, torch.float16, "x"), T, _dev(ids, torch.int32, "ids"), _dev(w, torch.float32, "w"), k,
         _dev(w13_q, torch.uint8, "w13_q"), _dev(w13_absmax, torch.float32, "w13_absmax"),
         _dev(w2_q, torch.uint8, "w2_q"), _dev(w2_absmax, torch.float32, "w2_absmax"), E_local, e_first, H, FF,
-        act_mode, flags, _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
+        act_mode, flags, None if b13 is None else _dev(b13, torch.float16, "b13"),
+        None if b2 is None else _dev(b2, torch.float16, "b2"), float(alpha), float(limit),
+        _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
         _dev(out, torch.float16, "out"), _stream()), "m355_moe_nf4_forward")
     return out
 

@@ -28,6 +28,10 @@ typedef void* m355_stream_t; /* a hipStream_t (NULL = the default stream) */
 #define M355_ACT_SILU_CONCAT 0 /* h = silu(gate) * up, gate = rows [0,FF), up = rows [FF,2FF) of W13:
                                   patches/unsloth_to_vllm_converter.py:312-315,
                                   patches/streaming_unsloth_bnb.py:269-270 */
+#define M355_ACT_SWIGLU_OAI 1  /* gpt-oss's own activation: gate = min(gate, limit), up = clamp(up, -limit, limit),
+                                  h = (up + 1) * gate * sigmoid(alpha * gate) (GptOssExperts._apply_gate,
+                                  transformers models/gpt_oss/modeling_gpt_oss.py:79-85); the reference replaces it
+                                  with plain silu (patches/unsloth_to_vllm_converter.py:312-315) */
 /* flags of m355_moe_nf4_forward */
 #define M355_FLAG_FP16_COMBINE 1 /* routing weights rounded to fp16 and out accumulated over k in fp16, in
                                     k order, as the reference's fp16 tensors do
@@ -66,6 +70,11 @@ M355_API int m355_nf4_dequant(const uint8_t* q, const float* absmax, int64_t n, 
  */
 M355_API int m355_repack_nf4(const uint8_t* q, const float* absmax, int rows, int cols, uint8_t* q_tiled,
                              float* absmax_tiled, m355_stream_t stream);
+/* row_order 1: the checkpoint interleaves gate and up rows (gate = rows 0, 2, 4, ..., up = rows 1, 3, 5, ..., as
+ * GptOssExperts stores gate_up_proj, modeling_gpt_oss.py:80); the tiled image still holds gate rows then up rows.
+ * row_order 0 is m355_repack_nf4. */
+M355_API int m355_repack_nf4_ex(const uint8_t* q, const float* absmax, int rows, int cols, int row_order,
+                                uint8_t* q_tiled, float* absmax_tiled, m355_stream_t stream);
 
 /*
  * Router: logits = fp16(x . wr^T + br), top-k by value (ties -> lower expert id), softmax over the k
@@ -95,6 +104,15 @@ M355_API int m355_moe_nf4_forward(const void* x_f16, int T, const int32_t* ids, 
                                   const uint8_t* w13_q, const float* w13_absmax, const uint8_t* w2_q,
                                   const float* w2_absmax, int E_local, int e_first, int H, int FF, int act_mode,
                                   int flags, void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream);
+/* The same with per-expert biases and the activation's constants: b13_f16 [E_local][2*FF] (gate entries, then up
+ * entries) is added to the gate_up product before the activation, b2_f16 [E_local][H] to the down product before
+ * the routing weight (GptOssExperts.forward, modeling_gpt_oss.py:109-112); either may be NULL.  alpha and limit
+ * are read by M355_ACT_SWIGLU_OAI only (gpt-oss: 1.702 and 7.0). */
+M355_API int m355_moe_nf4_forward_ex(const void* x_f16, int T, const int32_t* ids, const float* w, int k,
+                                     const uint8_t* w13_q, const float* w13_absmax, const uint8_t* w2_q,
+                                     const float* w2_absmax, int E_local, int e_first, int H, int FF, int act_mode,
+                                     int flags, const void* b13_f16, const void* b2_f16, float alpha, float limit,
+                                     void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream);
 M355_API size_t m355_moe_workspace_bytes(int T, int k, int H, int FF, int E_local);
 
 /*

@@ -242,6 +242,30 @@ def rope_rotate(x, cos, sin):
     return np.concatenate([first, second], axis=-1)
 
 
+def moe_forward_oai(x, ids, w, w13_f16, w2_f16, b13=None, b2=None, alpha: float = 1.702, limit: float = 7.0) -> np.ndarray:
+    """gpt-oss's own expert block (GptOssExperts.forward / _apply_gate, transformers
+    models/gpt_oss/modeling_gpt_oss.py:79-112) in fp32 numpy: w13_f16 [E][2FF][H] with gate rows at even and up
+    rows at odd positions, b13 [E][2FF] interleaved the same way, w2_f16 [E][H][FF], b2 [E][H].  Gate and up are
+    rounded to fp16 where the GEMM output would be; returns fp16 [T][H]."""
+    x = np.asarray(x, dtype=np.float16).astype(np.float32)
+    T, k = ids.shape
+    out = np.zeros((T, w2_f16.shape[1]), np.float32)
+    for t in range(T):
+        for j in range(k):
+            e = int(ids[t, j])
+            gu = np.asarray(w13_f16[e], dtype=np.float32) @ x[t]
+            if b13 is not None:
+                gu = gu + np.asarray(b13[e], dtype=np.float32)
+            gu = gu.astype(np.float16).astype(np.float32)
+            gate, up = np.minimum(gu[0::2], limit), np.clip(gu[1::2], -limit, limit)
+            h = ((up + 1.0) * gate / (1.0 + np.exp(-alpha * gate))).astype(np.float16).astype(np.float32)
+            y = np.asarray(w2_f16[e], dtype=np.float32) @ h
+            if b2 is not None:
+                y = y + np.asarray(b2[e], dtype=np.float32)
+            out[t] += np.float32(w[t, j]) * y.astype(np.float16).astype(np.float32)
+    return out.astype(np.float16)
+
+
 # ---------------------------------------------------------------------------------------------
 # bitsandbytes' own NF4 layout (the "true_bnb" loader mode).  bitsandbytes is not installed here and the
 # reference never reads a tensor this way (its loader takes the low nibble first and ignores nested_offset,
