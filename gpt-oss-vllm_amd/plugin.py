@@ -111,15 +111,22 @@ class Mi355Nf4MoEConfig(_QConfigBase):
     """4-bit NF4 for the MoE experts only; router and attention stay fp16 (patches/bnb_moe_4bit.py:22-56)."""
 
     LAYOUTS = ("reference", "true_bnb")
+    GATE_UP_ORDERS = ("concat", "interleaved")
 
-    def __init__(self, layout: str = "reference"):
+    def __init__(self, layout: str = "reference", gate_up_order: str = "concat"):
         """layout "reference": tensors are read as the reference's loader reads them (low nibble first, mean
         fallback for the nested scales, no offset) -- the parity contract.  "true_bnb": as bitsandbytes wrote
         them (high nibble first, one nested scale per 256 blocks, plus nested_offset)."""
         super().__init__()
         if layout not in self.LAYOUTS:
             raise ValueError(f"layout {layout!r}: expected one of {self.LAYOUTS}")
+        if gate_up_order not in self.GATE_UP_ORDERS:
+            raise ValueError(f"gate_up_order {gate_up_order!r}: expected one of {self.GATE_UP_ORDERS}")
         self.layout = layout
+        # "concat": gate = rows [0, FF), up = rows [FF, 2FF) of gate_up, as the reference splits it
+        # (patches/streaming_unsloth_bnb.py:269-270).  "interleaved": gate = even rows, up = odd rows, as gpt-oss
+        # itself stores it (transformers models/gpt_oss/modeling_gpt_oss.py:80); goes with activation="swigluoai".
+        self.gate_up_order = gate_up_order
         self.weight_bits = 4
         self.group_size = BLOCKSIZE
         self.compute_dtype = torch.float16
@@ -143,7 +150,8 @@ class Mi355Nf4MoEConfig(_QConfigBase):
 
     @classmethod
     def from_config(cls, config: Dict[str, Any]) -> "Mi355Nf4MoEConfig":
-        return cls(layout=(config or {}).get("layout", "reference"))
+        config = config or {}
+        return cls(layout=config.get("layout", "reference"), gate_up_order=config.get("gate_up_order", "concat"))
 
     def get_scaled_act_names(self) -> List[str]:
         return []
@@ -209,6 +217,7 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
             else:
                 setattr(layer, name, p)
         layer._m355_dims = (E, H, FF)
+        layer._m355_bias = {}         # "gate_up_proj_bias" | "down_proj_bias" -> fp16 [E][...] as loaded
         layer._m355_raw = {}          # (expert, "gate_up_projs"|"down_projs") -> {"weight"| suffix: tensor}
         layer._m355_ready = False
         layer._m355_ws = {}
@@ -219,6 +228,11 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
         names holding 'gate_up_projs' / 'down_projs' are parsed as
         model.layers.L.mlp.experts.<proj>.E.weight[.suffix]; the packed tensor is kept as loaded and converted
         later; returns `True if return_success else None`."""
+        for bias_name in ("gate_up_proj_bias", "down_proj_bias"):     # fused [E][...] tensors of the gpt-oss checkpoint
+            if weight_name.endswith(bias_name):
+                layer._m355_bias[bias_name] = loaded_weight
+                layer._m355_ready = False
+                return True if return_success else None
         if "gate_up_projs" not in weight_name and "down_projs" not in weight_name:
             raise ValueError(f"not an Unsloth per-expert MoE tensor: {weight_name}")
         parts = weight_name.split(".")
@@ -267,11 +281,27 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
                 am = resolve_absmax(t.get("absmax"), t.get("nested_absmax"), t.get("nested_quant_map")).reshape(-1)
             if am.numel() * BLOCKSIZE != rows * cols:
                 raise ValueError(f"expert {e} {proj}: {am.numel()} absmax entries, the kernels need one per {BLOCKSIZE}")
-            qt, at = lib.repack_nf4(q.to(dev).contiguous(), am.float().to(dev).contiguous(), rows, cols)
+            interleaved = proj == "gate_up_projs" and self.quant_config.gate_up_order == "interleaved"
+            qt, at = lib.repack_nf4(q.to(dev).contiguous(), am.float().to(dev).contiguous(), rows, cols,
+                                    row_order=1 if interleaved else 0)
             if proj == "gate_up_projs":
                 layer.w13_qweight.data[e], layer.w13_absmax.data[e] = qt, at
             else:
                 layer.w2_qweight.data[e], layer.w2_absmax.data[e] = qt, at
+        layer._m355_b13 = layer._m355_b2 = None
+        b13 = layer._m355_bias.get("gate_up_proj_bias")
+        if b13 is not None:
+            if tuple(b13.shape) != (E, 2 * FF):
+                raise ValueError(f"gate_up_proj_bias is {tuple(b13.shape)}, expected {(E, 2 * FF)}")
+            if self.quant_config.gate_up_order == "interleaved":      # the kernels want gate entries, then up entries
+                b13 = torch.cat([b13[:, 0::2], b13[:, 1::2]], dim=1)
+            layer._m355_b13 = b13.to(device=dev, dtype=torch.float16).contiguous()
+        b2 = layer._m355_bias.get("down_proj_bias")
+        if b2 is not None:
+            if tuple(b2.shape) != (E, H):
+                raise ValueError(f"down_proj_bias is {tuple(b2.shape)}, expected {(E, H)}")
+            layer._m355_b2 = b2.to(device=dev, dtype=torch.float16).contiguous()
+        layer._m355_bias = {}
         layer._m355_raw = {}
         layer._m355_ready = True
 
@@ -288,8 +318,9 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
         if not renormalize or use_grouped_topk or custom_routing_function is not None or scoring_func != "softmax" \
                 or e_score_correction_bias is not None or apply_router_weight_on_input:
             raise NotImplementedError("only top-k followed by softmax over the selected logits is implemented")
-        if activation != "silu":
-            raise NotImplementedError(f"activation {activation!r}: only silu(gate)*up over concatenated halves")
+        if activation not in ("silu", "swigluoai"):
+            raise NotImplementedError(f"activation {activation!r}: silu (the reference's) or swigluoai (gpt-oss's own)")
+        act_mode = lib.ACT_SILU_CONCAT if activation == "silu" else lib.ACT_SWIGLU_OAI
         E, H, FF = layer._m355_dims
         shape = x.shape
         x2 = x.reshape(-1, H)
@@ -311,7 +342,8 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
             layer._m355_ws = {T: ws}
         out = lib.moe_nf4_forward(x2.contiguous(), ids, w, layer.w13_qweight.data, layer.w13_absmax.data,
                                   layer.w2_qweight.data, layer.w2_absmax.data, E_local=E, e_first=e_first, H=H, FF=FF,
-                                  workspace=ws)
+                                  workspace=ws, act_mode=act_mode, b13=getattr(layer, "_m355_b13", None),
+                                  b2=getattr(layer, "_m355_b2", None))
         if in_dtype != torch.float16:
             out = out.to(in_dtype)
         return out.reshape(shape)

@@ -245,3 +245,32 @@ def test_gpu_experts_oai():
     a = lib.moe_nf4_forward(*args, E_local=Es, e_first=0, H=Hs, FF=FFs)
     b = lib.moe_nf4_forward(*args, E_local=Es, e_first=0, H=Hs, FF=FFs, b13=z13, b2=z2)
     assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_gpu_plugin_swigluoai():
+    """The same block through the plug-in surface: gate_up_order="interleaved", fused bias tensors handed to
+    weight_loader under their checkpoint names, apply(activation="swigluoai")."""
+    from gpt_oss_vllm_amd import checkpoint, plugin
+    cuda = torch.device("cuda:0")
+    Hs, FFs, Es, lay, b13, b2, xs, ids, wts = _oai_case()
+    method = plugin.Mi355Nf4MoEConfig(gate_up_order="interleaved").get_quant_method(None, "model.layers.0.mlp.experts")
+    layer = torch.nn.Module()
+    method.create_weights(layer, Es, Hs, FFs, torch.float16, device=cuda)
+    for e in range(Es):
+        for proj, tag in (("gate_up", "w13"), ("down", "w2")):
+            key = checkpoint.expert_weight_key(0, e, proj)
+            method.weight_loader(layer, None, torch.from_numpy(lay[tag + "_q"][e].copy()).reshape(-1, 1), key)
+            method.weight_loader(layer, None, torch.from_numpy(lay[tag + "_absmax"][e].copy()), key + ".absmax")
+    assert method.weight_loader(layer, None, torch.from_numpy(b13.copy()), "model.layers.0.mlp.experts.gate_up_proj_bias",
+                                return_success=True) is True
+    method.weight_loader(layer, None, torch.from_numpy(b2.copy()), "model.layers.0.mlp.experts.down_proj_bias")
+    method.process_weights_after_loading(layer)
+    lg = oracle_ref.normal_f16(oracle_ref.stream_seed(720, 4), (xs.shape[0], Es), 1.5)
+    out = method.apply(layer, torch.from_numpy(xs).to(cuda), torch.from_numpy(lg).to(cuda), top_k=2, renormalize=True,
+                       activation="swigluoai")
+    want = _g("layer_experts_oai.out.npy")
+    # the plug-in combines over k in fp16 as the reference does: one more fp16 rounding per term than the golden
+    assert np.abs(out.cpu().numpy().astype(np.float32) - want).max() <= 4e-3 * np.abs(want).max() + 1e-5
+    with pytest.raises(NotImplementedError):
+        method.apply(layer, torch.from_numpy(xs).to(cuda), torch.from_numpy(lg).to(cuda), top_k=2, activation="gelu")
