@@ -50,3 +50,74 @@ def rope_tables(max_pos: int, head_dim: int = 64, dtype: torch.dtype = torch.flo
     inv_freq, scaling = yarn_inv_freq(head_dim, **params)
     freqs = (inv_freq[:, None].float() @ torch.arange(max_pos)[None, :].float()).transpose(0, 1)
     return (freqs.cos() * scaling).to(dtype).contiguous(), (freqs.sin() * scaling).to(dtype).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# One gpt-oss decoder layer at decode time, as a fixed sequence of library calls on preallocated buffers
+# ---------------------------------------------------------------------------------------------
+class GptOssDecodeLayer:
+    """GptOssDecoderLayer.forward (transformers models/gpt_oss/modeling_gpt_oss.py:347-379) for one new token per
+    sequence: RMSNorm -> fused q/k/v projection -> rotary + KV-cache write -> paged attention (sinks, optional sliding
+    window) -> o projection + residual -> RMSNorm -> router top-k -> NF4 experts.  The second residual add is left to
+    the next layer's first RMSNorm call (or `finish`), which fuses it.
+
+    weights: dict with ln1, ln2 [H]; wqkv [(Hq + 2 Hkv) D][H], bqkv; wo [H][Hq D], bo; sinks [Hq] or None;
+    router_w [E][H], router_b [E] or None; w13_q, w13_absmax, w2_q, w2_absmax (tile order), b13 / b2 or None -- fp16
+    unless NF4.  Every intermediate lives in buffers sized for max_tokens, so a step allocates nothing and can be
+    captured in a HIP graph.
+    """
+
+    def __init__(self, weights, *, hidden: int, heads: int, kv_heads: int, head_dim: int, ffn: int, experts: int,
+                 top_k: int, max_tokens: int, eps: float = RMS_EPS, window: int = 0, act_mode: int = 1,
+                 device=None):
+        from . import lib
+        self.lib, self.w = lib, weights
+        self.H, self.Hq, self.Hkv, self.D, self.FF, self.E, self.k = hidden, heads, kv_heads, head_dim, ffn, experts, top_k
+        self.eps, self.window, self.act_mode, self.T = eps, window, act_mode, max_tokens
+        dev = device if device is not None else weights["wqkv"].device
+        f16 = dict(dtype=torch.float16, device=dev)
+        T = max_tokens
+        self.h1 = torch.empty((T, hidden), **f16)
+        self.resid = torch.empty((T, hidden), **f16)
+        self.qkv = torch.empty((T, (heads + 2 * kv_heads) * head_dim), **f16)
+        self.q = torch.empty((T, heads, head_dim), **f16)
+        self.attn = torch.empty((T, heads, head_dim), **f16)
+        self.resid2 = torch.empty((T, hidden), **f16)
+        self.h2 = torch.empty((T, hidden), **f16)
+        self.ids = torch.empty((T, top_k), dtype=torch.int32, device=dev)
+        self.wts = torch.empty((T, top_k), dtype=torch.float32, device=dev)
+        self.moe_out = torch.empty((T, hidden), **f16)
+        self.moe_ws = torch.empty(max(256, lib.moe_workspace_bytes(T, top_k, hidden, ffn, experts)), dtype=torch.uint8, device=dev)
+        self.attn_ws = None
+
+    def write_kv_only(self, x, positions, slots, kcache, vcache, cos, sin):
+        """RMSNorm + q/k/v projection + rotary + cache write for tokens whose attention output is not needed
+        (filling the cache with a prompt through the decode kernels)."""
+        lib, w = self.lib, self.w
+        h = lib.add_rmsnorm(x, None, w["ln1"], self.eps)
+        qkv = lib.linear_f16(h, w["wqkv"], w.get("bqkv"))
+        lib.rope_kv_write(qkv, cos, sin, positions, slots, kcache, vcache, Hq=self.Hq, Hkv=self.Hkv, D=self.D)
+
+    def forward(self, resid_in, delta, positions, slots, block_tables, ctx_lens, kcache, vcache, cos, sin, max_ctx: int):
+        """resid_in [T][H]: the residual stream entering the layer, delta: the previous layer's expert output still to
+        be added (None for the first layer).  ctx_lens counts the new token.  Returns (residual stream after
+        attention, expert output): their sum is the layer's output."""
+        lib, w = self.lib, self.w
+        T = resid_in.shape[0]
+        if T != self.T:
+            raise ValueError(f"built for {self.T} tokens per step, got {T}")
+        lib.add_rmsnorm(resid_in, delta, w["ln1"], self.eps, resid_out=self.resid, out=self.h1)
+        lib.linear_f16(self.h1, w["wqkv"], w.get("bqkv"), out=self.qkv)
+        lib.rope_kv_write(self.qkv, cos, sin, positions, slots, kcache, vcache, Hq=self.Hq, Hkv=self.Hkv, D=self.D, q_out=self.q)
+        need = lib.paged_attn_workspace_bytes(T, self.Hq, self.D, max_ctx)
+        if need and (self.attn_ws is None or self.attn_ws.numel() < need):
+            self.attn_ws = torch.empty(need, dtype=torch.uint8, device=self.q.device)
+        lib.paged_attn_decode(self.q, kcache, vcache, block_tables, ctx_lens, max_ctx=max_ctx, scale=self.D ** -0.5,
+                              workspace=self.attn_ws, out=self.attn, sinks=w.get("sinks"), window=self.window)
+        lib.linear_f16(self.attn.view(T, self.Hq * self.D), w["wo"], w.get("bo"), resid=self.resid, out=self.resid2)
+        lib.add_rmsnorm(self.resid2, None, w["ln2"], self.eps, out=self.h2)
+        lib.router_topk(self.h2, w["router_w"], w.get("router_b"), self.k, ids=self.ids, w=self.wts)
+        lib.moe_nf4_forward(self.h2, self.ids, self.wts, w["w13_q"], w["w13_absmax"], w["w2_q"], w["w2_absmax"],
+                            E_local=self.E, e_first=0, H=self.H, FF=self.FF, workspace=self.moe_ws, out=self.moe_out,
+                            act_mode=self.act_mode, flags=0, b13=w.get("b13"), b2=w.get("b2"))
+        return self.resid2, self.moe_out

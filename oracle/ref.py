@@ -474,3 +474,22 @@ def golden_forward_case(name: str) -> dict:
     x = normal_f16(stream_seed(sd, 21), (T, H), 1.0)
     logits = normal_f16(stream_seed(sd, 22), (T, E), 1.5)
     return dict(H=H, FF=FF, E=E, k=k, T=T, x=x, logits=logits, **layer)
+
+
+def decoder_layer_case(name):
+    """Seeded parameters and inputs of the whole-decoder-layer cases ("sliding", "full"): what
+    tests/golden/make_layer_golden.py fed to transformers' GptOssDecoderLayer and what the GPU tests feed to the kernels."""
+    H_, FF_, E_, k_, Hq_, Hkv_, D_, L_, window = 256, 192, 4, 2, 8, 1, 64, 200, 128
+    sd = stream_seed(730, 0 if name == "sliding" else 1)
+    n = lambda i, shape, std: normal_f16(stream_seed(sd, i), shape, std)
+    lay = synth_layer(stream_seed(sd, 50), E_, H_, FF_)
+    return dict(
+        H=H_, FF=FF_, E=E_, k=k_, Hq=Hq_, Hkv=Hkv_, D=D_, L=L_, window=window, lay=lay,
+        ln1=(1.0 + 0.1 * n(1, (H_,), 1.0).astype(np.float32)).astype(np.float16),
+        ln2=(1.0 + 0.1 * n(2, (H_,), 1.0).astype(np.float32)).astype(np.float16),
+        wqkv=n(3, ((Hq_ + 2 * Hkv_) * D_, H_), 0.06), bqkv=n(4, ((Hq_ + 2 * Hkv_) * D_,), 0.1),
+        wo=n(5, (H_, Hq_ * D_), 0.04), bo=n(6, (H_,), 0.1), sinks=n(7, (Hq_,), 1.0),
+        router_w=n(8, (E_, H_), 0.1), router_b=n(9, (E_,), 0.1),
+        b13=n(10, (E_, 2 * FF_), 0.3), b2=n(11, (E_, H_), 0.3), x=n(12, (L_ + 1, H_), 1.0),
+        w13_f16=np.stack([nf4_dequant(lay["w13_q"][e], 2 * FF_ * H_, lay["w13_absmax"][e]).reshape(2 * FF_, H_) for e in range(E_)]),
+        w2_f16=np.stack([nf4_dequant(lay["w2_q"][e], H_ * FF_, lay["w2_absmax"][e]).reshape(H_, FF_) for e in range(E_)]))

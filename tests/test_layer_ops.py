@@ -274,3 +274,47 @@ def test_gpu_plugin_swigluoai():
     assert np.abs(out.cpu().numpy().astype(np.float32) - want).max() <= 4e-3 * np.abs(want).max() + 1e-5
     with pytest.raises(NotImplementedError):
         method.apply(layer, torch.from_numpy(xs).to(cuda), torch.from_numpy(lg).to(cuda), top_k=2, activation="gelu")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["sliding", "full"])
+def test_gpu_whole_decoder_layer_vs_transformers(name):
+    """200 prompt tokens are written into the paged cache through the layer's own norm / projection / rotary
+    kernels, then one new token goes through the whole layer; the result is the last row of transformers'
+    GptOssDecoderLayer run over the 201-token sequence in fp32 (sliding-window layer and full-attention layer)."""
+    from gpt_oss_vllm_amd import layer, lib
+    cuda = torch.device("cuda:0")
+    p = oracle_ref.decoder_layer_case(name)
+    H_, FF_, E_, L = p["H"], p["FF"], p["E"], p["L"]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    w13_q, w13_a, w2_q, w2_a = [], [], [], []
+    for e in range(E_):
+        qt, at = lib.repack_nf4(dev(p["lay"]["w13_q"][e]), dev(p["lay"]["w13_absmax"][e]), 2 * FF_, H_, row_order=1)
+        w13_q.append(qt), w13_a.append(at)
+        qt, at = lib.repack_nf4(dev(p["lay"]["w2_q"][e]), dev(p["lay"]["w2_absmax"][e]), H_, FF_)
+        w2_q.append(qt), w2_a.append(at)
+    weights = dict(ln1=dev(p["ln1"]), ln2=dev(p["ln2"]), wqkv=dev(p["wqkv"]), bqkv=dev(p["bqkv"]), wo=dev(p["wo"]), bo=dev(p["bo"]),
+                   sinks=dev(p["sinks"]), router_w=dev(p["router_w"]), router_b=dev(p["router_b"]),
+                   w13_q=torch.stack(w13_q), w13_absmax=torch.stack(w13_a), w2_q=torch.stack(w2_q), w2_absmax=torch.stack(w2_a),
+                   b13=dev(np.concatenate([p["b13"][:, 0::2], p["b13"][:, 1::2]], axis=1)), b2=dev(p["b2"]))
+    lyr = layer.GptOssDecodeLayer(weights, hidden=H_, heads=p["Hq"], kv_heads=p["Hkv"], head_dim=p["D"], ffn=FF_, experts=E_,
+                                  top_k=p["k"], max_tokens=1, window=p["window"] if name == "sliding" else 0,
+                                  act_mode=lib.ACT_SWIGLU_OAI)
+    block_size = 16
+    nblk = (L + 1 + block_size - 1) // block_size
+    perm = np.random.default_rng(3).permutation(nblk).astype(np.int32)
+    kc = torch.zeros((nblk, block_size, p["Hkv"], p["D"]), dtype=torch.float16, device=cuda)
+    vc = torch.zeros_like(kc)
+    cos, sin = layer.rope_tables(512)
+    cos, sin = cos.to(cuda), sin.to(cuda)
+    slot_of = lambda t: int(perm[t // block_size]) * block_size + t % block_size
+    x = dev(p["x"])
+    lyr.write_kv_only(x[:L].contiguous(), torch.arange(L, dtype=torch.int32, device=cuda),
+                      torch.tensor([slot_of(t) for t in range(L)], dtype=torch.int64, device=cuda), kc, vc, cos, sin)
+    resid2, moe_out = lyr.forward(x[L:].contiguous(), None, torch.tensor([L], dtype=torch.int32, device=cuda),
+                                  torch.tensor([slot_of(L)], dtype=torch.int64, device=cuda), dev(perm[None, :].copy()),
+                                  torch.tensor([L + 1], dtype=torch.int32, device=cuda), kc, vc, cos, sin, max_ctx=L + 1)
+    torch.cuda.synchronize()
+    got = (resid2.float() + moe_out.float()).cpu().numpy()[0]
+    want = _g(f"layer_decoder.{name}.npy")
+    assert np.abs(got - want).max() <= 5e-3 * np.abs(want).max()
