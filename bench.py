@@ -222,6 +222,69 @@ def cpu_baseline():
     }
 
 
+def full_layer_leg(lib, main_step, batch, ctx, layers, device, steps, warmup):
+    """The whole decoder stack at decode time (every layer: norm, q/k/v projection, rotary + cache write, attention
+    with sinks, o projection, norm, router, NF4 experts with gpt-oss's own activation and biases), one HIP graph;
+    embedding and lm_head are not part of it.  NF4 expert tensors are shared with the hot-path legs."""
+    from gpt_oss_vllm_amd import layer as layer_mod
+    g = torch.Generator(device=device)
+    g.manual_seed(4242)
+    rnd = lambda shape, std: (torch.randn(shape, device=device, generator=g) * std).half()
+    nblk_seq = (ctx + BLOCK) // BLOCK + 1
+    block_tables = torch.randperm(batch * nblk_seq, device=device, generator=g).to(torch.int32).reshape(batch, nblk_seq).contiguous()
+    ctx_lens = torch.full((batch,), ctx + 1, dtype=torch.int32, device=device)      # the new token is position ctx
+    positions = torch.full((batch,), ctx, dtype=torch.int32, device=device)
+    slots = (block_tables[:, ctx // BLOCK].to(torch.int64) * BLOCK + ctx % BLOCK).contiguous()
+    cos, sin = layer_mod.rope_tables(ctx + 2)
+    cos, sin = cos.to(device), sin.to(device)
+    stack = []
+    for li in range(layers):
+        src = main_step.L[li]
+        w = dict(ln1=rnd((H,), 0.1) + 1, ln2=rnd((H,), 0.1) + 1, wqkv=rnd(((HQ + 2 * HKV) * D, H), 0.02), bqkv=rnd(((HQ + 2 * HKV) * D,), 0.02),
+                 wo=rnd((H, HQ * D), 0.02), bo=rnd((H,), 0.02), sinks=rnd((HQ,), 1.0), router_w=src["wr"], router_b=rnd((E,), 0.02),
+                 w13_q=src["w13_q"], w13_absmax=src["w13_a"], w2_q=src["w2_q"], w2_absmax=src["w2_a"],
+                 b13=rnd((E, 2 * FF), 0.02), b2=rnd((E, H), 0.02))
+        lyr = layer_mod.GptOssDecodeLayer(w, hidden=H, heads=HQ, kv_heads=HKV, head_dim=D, ffn=FF, experts=E, top_k=TOPK,
+                                          max_tokens=batch, window=128 if li % 2 == 0 else 0, act_mode=lib.ACT_SWIGLU_OAI)
+        # this leg's block tables address one block more per sequence than the hot-path legs' caches hold
+        kc = rnd((batch * nblk_seq, BLOCK, HKV, D), 1.0)
+        vc = rnd((batch * nblk_seq, BLOCK, HKV, D), 1.0)
+        stack.append((lyr, kc, vc))
+    x0 = rnd((batch, H), 1.0)
+    layer_mod.validate_paging(block_tables, slots, ctx_lens, stack[0][1])     # host check before anything is launched
+
+    def run():
+        resid, delta = x0, None
+        for lyr, kc, vc in stack:
+            resid, delta = lyr.forward(resid, delta, positions, slots, block_tables, ctx_lens, kc, vc, cos, sin, max_ctx=ctx + 1)
+        return resid, delta
+
+    run()
+    torch.cuda.synchronize()
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        run()
+    torch.cuda.current_stream().wait_stream(s_)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run()
+    for _ in range(warmup):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    dense_bytes = layers * 2 * (((HQ + 2 * HKV) * D) * H + H * HQ * D)
+    return {"value": batch / dt, "unit": "tokens/s", "ms_per_step": dt * 1e3, "batch": batch, "ctx": ctx,
+            "what": "24 whole decoder layers per step (dense q/k/v/o projections, rotary + KV write, attention with sinks and "
+                    "alternating 128-token sliding window, norms, router, NF4 experts with swiglu-oai and biases), one HIP graph",
+            "dense_projection_bytes_per_step": dense_bytes}
+
+
 def load_leg(device):
     """Checkpoint -> GPU-resident tile-order weights for one full-size layer (32 experts): a synthetic shard in the
     Unsloth key schema is written to a temporary directory, then read through the plug-in's weight_loader and
@@ -269,6 +332,7 @@ def main():
     ap.add_argument("--no-bs1", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--load-leg", action="store_true", help="also time checkpoint -> GPU weights for one layer")
+    ap.add_argument("--full-layer-leg", action="store_true", help="also time the whole decoder stack (bs = --batch-per-gpu and 1)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -349,6 +413,9 @@ def main():
         }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
+    if rank == 0 and world == 1 and a.full_layer_leg:
+        result["full_decoder_stack"] = [full_layer_leg(lib, main_step, b, a.ctx, a.layers, device, a.steps, a.warmup)
+                                        for b in (a.batch_per_gpu, 1)]
     if rank == 0 and world == 1 and a.load_leg:
         result["load"] = load_leg(device)
 

@@ -52,6 +52,26 @@ def rope_tables(max_pos: int, head_dim: int = 64, dtype: torch.dtype = torch.flo
     return (freqs.cos() * scaling).to(dtype).contiguous(), (freqs.sin() * scaling).to(dtype).contiguous()
 
 
+def validate_paging(block_tables: torch.Tensor, slots: torch.Tensor, ctx_lens: torch.Tensor, kcache: torch.Tensor) -> None:
+    """Host-side check (synchronises) that the paging metadata stays inside the cache: the kernels trust it, and an
+    out-of-range block id is an out-of-bounds access on the GPU.  Meant to run once per configuration, before the
+    step is launched or captured."""
+    nblocks, block_size = kcache.shape[0], kcache.shape[1]
+    bt = block_tables.detach().cpu()
+    used = (ctx_lens.detach().cpu().to(torch.int64) + block_size - 1) // block_size
+    if bt.shape[0] != used.numel():
+        raise ValueError(f"block_tables has {bt.shape[0]} rows for {used.numel()} sequences")
+    if int(used.max()) > bt.shape[1]:
+        raise ValueError(f"a context of {int(ctx_lens.max())} tokens needs {int(used.max())} blocks, block_tables holds {bt.shape[1]}")
+    for b in range(bt.shape[0]):
+        row = bt[b, :int(used[b])]
+        if row.numel() and (int(row.min()) < 0 or int(row.max()) >= nblocks):
+            raise ValueError(f"sequence {b}: block id outside [0, {nblocks})")
+    sl = slots.detach().cpu()
+    if int(sl.max()) >= nblocks * block_size:
+        raise ValueError(f"slot {int(sl.max())} outside the cache of {nblocks * block_size} rows")
+
+
 # ---------------------------------------------------------------------------------------------
 # One gpt-oss decoder layer at decode time, as a fixed sequence of library calls on preallocated buffers
 # ---------------------------------------------------------------------------------------------
