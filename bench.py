@@ -53,7 +53,8 @@ def profiled_traffic():
 class DecodeStep:
     """State and launch sequence of one decode step for `batch` sequences per rank."""
 
-    def __init__(self, lib, ep_mod, batch, ctx, layers, rank, world, device, group=None, weights_from=None):
+    def __init__(self, lib, ep_mod, batch, ctx, layers, rank, world, device, group=None, weights_from=None,
+                 force_exchange=False):
         self.lib, self.batch, self.ctx, self.layers = lib, batch, ctx, layers
         self.world, self.rank, self.device = world, rank, device
         g = torch.Generator(device=device)
@@ -86,7 +87,8 @@ class DecodeStep:
             lay["attn_out"] = torch.empty((B, HQ, D), dtype=torch.float16, device=device)
             lay["out"] = torch.empty((B, H), dtype=torch.float16, device=device)
             lay["ep"] = ep_mod.ExpertParallelMoE((lay["w13_q"], lay["w13_a"], lay["w2_q"], lay["w2_a"]), num_experts=E,
-                                                 top_k=TOPK, hidden=H, ffn=FF, max_tokens=B, group=group, device=device)
+                                                 top_k=TOPK, hidden=H, ffn=FF, max_tokens=B, group=group, device=device,
+                                                 force_exchange=force_exchange)
             self.L.append(lay)
         self.graph = None
 
@@ -331,6 +333,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bs1", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="one-rank rehearsal of the multi-GPU path: initialise RCCL and run the token exchange even at --gpus 1")
+    ap.add_argument("--graph-dist", action="store_true", help="capture the step in a HIP graph even when it holds collectives")
     ap.add_argument("--load-leg", action="store_true", help="also time checkpoint -> GPU weights for one layer")
     ap.add_argument("--full-layer-leg", action="store_true", help="also time the whole decoder stack (bs = --batch-per-gpu and 1)")
     a = ap.parse_args()
@@ -345,18 +350,20 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+    if world > 1 or a.force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
 
     import gpt_oss_vllm_amd  # noqa: F401
     from gpt_oss_vllm_amd import ep as ep_mod
     from gpt_oss_vllm_amd import lib
     lib.load()
 
-    main_step = DecodeStep(lib, ep_mod, a.batch_per_gpu, a.ctx, a.layers, rank, world, device)
+    main_step = DecodeStep(lib, ep_mod, a.batch_per_gpu, a.ctx, a.layers, rank, world, device, force_exchange=a.force_dist)
     main_step.run_eager()          # first call sets kernel attributes; must precede graph capture
     torch.cuda.synchronize()
-    use_graph = (world == 1) and not a.eager
+    use_graph = ((world == 1 and not a.force_dist) or a.graph_dist) and not a.eager
     if use_graph:
         main_step.capture()
     dt = timed(main_step, a.steps, a.warmup, world)
@@ -379,7 +386,8 @@ def main():
         # BASELINE configs[1]: bs=1 greedy decode, seq_len 256 (per GPU when N > 1)
         del main_step.graph
         main_step.graph = None
-        bs1 = DecodeStep(lib, ep_mod, 1, a.ctx, a.layers, rank, world, device, weights_from=main_step)
+        bs1 = DecodeStep(lib, ep_mod, 1, a.ctx, a.layers, rank, world, device, weights_from=main_step,
+                         force_exchange=a.force_dist)
         bs1.run_eager()
         torch.cuda.synchronize()
         if use_graph:
@@ -421,7 +429,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if world > 1 or a.force_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -55,7 +55,8 @@ class ExpertParallelMoE:
     """One MoE layer's expert shard plus the buffers of its token exchange (allocated once, reused)."""
 
     def __init__(self, weights, *, num_experts: int, top_k: int, hidden: int, ffn: int, max_tokens: int,
-                 group: Optional[dist.ProcessGroup] = None, ops=None, device=None, flags: int = 1):
+                 group: Optional[dist.ProcessGroup] = None, ops=None, device=None, flags: int = 1,
+                 force_exchange: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -67,6 +68,9 @@ class ExpertParallelMoE:
         self.weights = weights          # (w13_q, w13_absmax, w2_q, w2_absmax) of the local experts, tile order
         self.ops = ops if ops is not None else HipOps()
         self.flags = flags
+        # a single rank normally skips the exchange; force_exchange runs pack / all-to-all / unpack / reduce anyway
+        # (a one-rank rehearsal of the multi-GPU path, needs an initialised process group)
+        self.force_exchange = force_exchange and dist.is_initialized()
         self.T = max_tokens
         dev = device if device is not None else weights[0].device
         N, T, H, k = self.world, max_tokens, hidden, top_k
@@ -91,7 +95,7 @@ class ExpertParallelMoE:
         N, H, k = self.world, self.H, self.k
         if out is None:
             out = torch.empty((T, H), dtype=torch.float16, device=x.device)
-        if N == 1:
+        if N == 1 and not self.force_exchange:
             self.ops.moe(x, ids, w, self.weights, self.epr, 0, H, self.FF, self.workspace, out, self.flags)
             return out
         self.ops.pack(x, ids, w, N, self.epr, self.send)
