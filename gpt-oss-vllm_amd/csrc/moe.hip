@@ -528,10 +528,9 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     InlineTables* rt = reinterpret_cast<InlineTables*>(red + RED_ALL);
     int te_lane = 0;
     if constexpr (INLINE) {
-        // the ids are requested first; the code table is built while they are on their way
+        // the ids are requested first; the code table is built later, while the first weights are on their way
         int my_e = -1;
         if ((int)threadIdx.x < rio.P) my_e = rio.ids[threadIdx.x] - rio.e_first;
-        build_lutp(lut, red, threadIdx.x, THREADS);
         if (my_e >= rio.E_local) my_e = -1;
         inline_route(rio, my_e, mt_rows, reinterpret_cast<uint32_t*>(red), rt, threadIdx.x, THREADS);
     } else {
@@ -607,7 +606,7 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     sA = sAn;
     sB = sBn;
 
-    if constexpr (!INLINE) build_lutp(lut, red, tid, THREADS);   // (while the first weights are on their way)
+    build_lutp(lut, red, tid, THREADS);   // (while the first weights are on their way)
     const uint32_t lbase = lutp_lane_base(smem, lane);
 
     // Every wave runs MOE_CHUNK blocks per item without branches.  Per block: M355_FETCH (16 table lookups = four A
