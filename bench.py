@@ -54,7 +54,7 @@ class DecodeStep:
     """State and launch sequence of one decode step for `batch` sequences per rank."""
 
     def __init__(self, lib, ep_mod, batch, ctx, layers, rank, world, device, group=None, weights_from=None,
-                 force_exchange=False):
+                 force_exchange=False, absmax="u8"):
         self.lib, self.batch, self.ctx, self.layers = lib, batch, ctx, layers
         self.world, self.rank, self.device = world, rank, device
         g = torch.Generator(device=device)
@@ -74,9 +74,15 @@ class DecodeStep:
                     lay[key] = weights_from.L[li][key]
             else:
                 lay["w13_q"] = torch.randint(0, 256, (e_local, FF * H), dtype=torch.uint8, device=device, generator=g)
-                lay["w13_a"] = torch.rand((e_local, 2 * FF * H // 64), dtype=torch.float32, device=device, generator=g) * 0.03
                 lay["w2_q"] = torch.randint(0, 256, (e_local, H * FF // 2), dtype=torch.uint8, device=device, generator=g)
-                lay["w2_a"] = torch.rand((e_local, H * FF // 64), dtype=torch.float32, device=device, generator=g) * 0.03
+                if absmax == "u8":   # as the checkpoint stores it: a code byte per block + a 256-entry table per expert
+                    lay["w13_a"] = (torch.randint(0, 256, (e_local, 2 * FF * H // 64), dtype=torch.uint8, device=device, generator=g),
+                                    torch.rand((e_local, 256), dtype=torch.float32, device=device, generator=g) * 0.03)
+                    lay["w2_a"] = (torch.randint(0, 256, (e_local, H * FF // 64), dtype=torch.uint8, device=device, generator=g),
+                                   torch.rand((e_local, 256), dtype=torch.float32, device=device, generator=g) * 0.03)
+                else:
+                    lay["w13_a"] = torch.rand((e_local, 2 * FF * H // 64), dtype=torch.float32, device=device, generator=g) * 0.03
+                    lay["w2_a"] = torch.rand((e_local, H * FF // 64), dtype=torch.float32, device=device, generator=g) * 0.03
             lay["wr"] = (torch.randn((E, H), device=device, generator=g) * 0.02).half()
             lay["x"] = torch.randn((B, H), device=device, generator=g).half()
             lay["q"] = torch.randn((B, HQ, D), device=device, generator=g).half()
@@ -330,6 +336,9 @@ def main():
     ap.add_argument("--ctx", type=int, default=256)
     ap.add_argument("--layers", type=int, default=LAYERS)
     ap.add_argument("--eager", action="store_true", help="do not capture the step in a HIP graph")
+    ap.add_argument("--absmax", choices=("u8", "fp32"), default="u8",
+                    help="absmax storage: u8 = the checkpoint's code byte per block + a 256-entry table per expert (default), "
+                         "fp32 = one un-double-quantised fp32 per block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bs1", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -360,7 +369,8 @@ def main():
     from gpt_oss_vllm_amd import lib
     lib.load()
 
-    main_step = DecodeStep(lib, ep_mod, a.batch_per_gpu, a.ctx, a.layers, rank, world, device, force_exchange=a.force_dist)
+    main_step = DecodeStep(lib, ep_mod, a.batch_per_gpu, a.ctx, a.layers, rank, world, device, force_exchange=a.force_dist,
+                           absmax=a.absmax)
     main_step.run_eager()          # first call sets kernel attributes; must precede graph capture
     torch.cuda.synchronize()
     use_graph = ((world == 1 and not a.force_dist) or a.graph_dist) and not a.eager
@@ -379,6 +389,7 @@ def main():
                          + ("1 GPU: BASELINE configs[2]" if world == 1 else f"experts sharded over {world} GPUs (EP, all-to-all): BASELINE configs[3] shape")),
             "batch_per_gpu": a.batch_per_gpu, "global_batch": tokens, "seq_len": a.ctx,
             "parallelism": "single" if world == 1 else f"ep{world}+dp{world}", "hip_graph": use_graph,
+            "absmax_storage": a.absmax,
         },
     }
 

@@ -89,6 +89,24 @@ __global__ __launch_bounds__(256) void repack_absmax_kernel(const float* __restr
     at[o] = a[(int64_t)row * NB + b];
 }
 
+__global__ __launch_bounds__(256) void repack_absmax_u8_kernel(const uint8_t* __restrict__ a, int rows, int cols, int row_order,
+                                                               uint8_t* __restrict__ at) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int NB = cols / 64, P = rows / 32;
+    const int64_t total = (int64_t)rows * NB;
+    if (o >= total) return;
+    const int i = (int)(o & 3);
+    int64_t t = o >> 2;
+    const int b = (int)(t % NB);
+    t /= NB;
+    const int g = (int)(t & 3);
+    t >>= 2;
+    const int half = (int)(t & 1);
+    const int p = (int)(t >> 1);
+    const int row = source_row(16 * (p + half * P) + 4 * g + i, rows, row_order);
+    at[o] = a[(int64_t)row * NB + b];
+}
+
 }  // namespace m355
 
 using namespace m355;
@@ -130,5 +148,18 @@ extern "C" int m355_repack_nf4_ex(const uint8_t* q, const float* absmax, int row
     repack_absmax_kernel<<<dim3((unsigned)((na + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(absmax, rows, cols, row_order,
                                                                                                    absmax_tiled);
     M355_LAUNCH_CHECK("m355_repack_nf4(absmax)");
+    return 0;
+}
+
+extern "C" int m355_repack_absmax_u8(const uint8_t* absmax_u8, int rows, int cols, int row_order, uint8_t* absmax_tiled,
+                                     m355_stream_t stream) {
+    if (!absmax_u8 || !absmax_tiled) return fail(-1, "m355_repack_absmax_u8: null pointer");
+    if (rows <= 0 || cols <= 0 || (rows % 32) || (cols % 64) || (row_order != 0 && row_order != 1))
+        return fail(-2, "m355_repack_absmax_u8: need rows %% 32 == 0, cols %% 64 == 0, row_order 0 or 1 (rows=%d, cols=%d)", rows, cols);
+    if (absmax_u8 == absmax_tiled) return fail(-4, "m355_repack_absmax_u8: in-place repack is not supported");
+    const int64_t na = (int64_t)rows * (cols / 64);
+    repack_absmax_u8_kernel<<<dim3((unsigned)((na + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(absmax_u8, rows, cols,
+                                                                                                      row_order, absmax_tiled);
+    M355_LAUNCH_CHECK("m355_repack_absmax_u8");
     return 0;
 }

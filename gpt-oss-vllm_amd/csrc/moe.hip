@@ -519,7 +519,8 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     const half_t* __restrict__ xin, const uint8_t* __restrict__ wq, const float* __restrict__ wam,
     const int32_t* __restrict__ n_tiles, const int32_t* __restrict__ tile_expert, const int32_t* __restrict__ tile_m0,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ sorted, int K, int R, int k_top, int mt_rows,
-    half_t* __restrict__ outp, int table_len, RouteIO rio, StageParams sp) {
+    half_t* __restrict__ outp, int table_len, RouteIO rio, StageParams sp, const uint8_t* __restrict__ wam8,
+    const float* __restrict__ wtab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int THREADS = PAIRS * 256;
     constexpr int RED_ALL = 2 * PAIRS * (MOE_KPARTS - 1) * 64 * 8 * 4;   // both reduction buffers
@@ -578,18 +579,40 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
 #pragma unroll
     for (int i = 0; i < MOE_CHUNK; i++) voff[i] = (uint32_t)lane * 16u + (uint32_t)(min(bq0 + i, blast) - bq0) * 1024u;
 
-    // aim the ring loads at item IT and request its absmax: lane (n, g) gets rows 4g..4g+3 of both tiles at block bq0 + n
+    // aim the ring loads at item IT and request its absmax: lane (n, g) gets rows 4g..4g+3 of both tiles at block
+    // bq0 + n.  The absmax is either fp32 (wam) or, as the checkpoint stores it, one code byte per block (wam8, same
+    // tile order, 4 bytes per lane) with a 256-entry fp32 table per expert (wtab): then the table values of item IT
+    // are gathered with the codes requested one call earlier, and the codes of item IT + 1 are requested now, so
+    // neither load waits for the other.
+    uint32_t cAn = 0, cBn = 0;
+    const int bs_lane = min(bq0 + n, blast);
+    const float keep_lane = (bq0 + n < bq1) ? 1.f : 0.f;   // blocks past the K-part count for nothing
+#define M355_CODES_OF(IT)                                                                                     \
+    {                                                                                                         \
+        const int itc_ = min((IT), it1 - 1);                                                                  \
+        const int tt_ = itc_ / NPG, pg_ = itc_ - tt_ * NPG;                                                   \
+        const int e_ = M355_TILE_EXPERT(tt_);                                                                 \
+        const int pc_ = min(pg_ * PAIRS + pl, NP - 1);                                                        \
+        const uint32_t* cm_ = reinterpret_cast<const uint32_t*>(wam8 + (size_t)e_ * am_expert);               \
+        cAn = cm_[((size_t)(pc_ * 2 + 0) * 4 + g) * NB + bs_lane];                                            \
+        cBn = cm_[((size_t)(pc_ * 2 + 1) * 4 + g) * NB + bs_lane];                                            \
+    }
 #define M355_POINT_AT(IT)                                                                                     \
     {                                                                                                         \
         const int tt_ = (IT) / NPG, pg_ = (IT) - tt_ * NPG;                                                   \
         const int e_ = M355_TILE_EXPERT(tt_);                                                                 \
         const int pc_ = min(pg_ * PAIRS + pl, NP - 1);                                                        \
         wbase_next = wq + (size_t)e_ * wq_expert + ((size_t)pc_ * NB + bq0) * 1024;                           \
-        const float4_t* am_ = reinterpret_cast<const float4_t*>(wam + (size_t)e_ * am_expert);                \
-        const int bs_ = min(bq0 + n, blast);                                                                  \
-        const float keep_ = (bq0 + n < bq1) ? 1.f : 0.f; /* blocks past the K-part count for nothing */       \
-        sAn = am_[((size_t)(pc_ * 2 + 0) * 4 + g) * NB + bs_] * keep_;                                        \
-        sBn = am_[((size_t)(pc_ * 2 + 1) * 4 + g) * NB + bs_] * keep_;                                        \
+        if (wam8) {                                                                                           \
+            const float* tab_ = wtab + (size_t)e_ * 256;                                                      \
+            sAn = float4_t{tab_[cAn & 0xffu], tab_[(cAn >> 8) & 0xffu], tab_[(cAn >> 16) & 0xffu], tab_[cAn >> 24]} * keep_lane; \
+            sBn = float4_t{tab_[cBn & 0xffu], tab_[(cBn >> 8) & 0xffu], tab_[(cBn >> 16) & 0xffu], tab_[cBn >> 24]} * keep_lane; \
+            M355_CODES_OF((IT) + 1)                                                                           \
+        } else {                                                                                              \
+            const float4_t* am_ = reinterpret_cast<const float4_t*>(wam + (size_t)e_ * am_expert);            \
+            sAn = am_[((size_t)(pc_ * 2 + 0) * 4 + g) * NB + bs_lane] * keep_lane;                            \
+            sBn = am_[((size_t)(pc_ * 2 + 1) * 4 + g) * NB + bs_lane] * keep_lane;                            \
+        }                                                                                                     \
     }
     // (the empty asm keeps the offset a 32-bit register at the point of use, which is what lets the compiler pick
     // the SGPR-base + VGPR-offset addressing form instead of widening the offsets to 64 bits outside the loop)
@@ -600,6 +623,7 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     }
 #define M355_NO_LOAD(I)
 
+    if (wam8) M355_CODES_OF(it0)
     M355_POINT_AT(it0)
 #pragma unroll
     for (int i = 0; i < MOE_CHUNK; i++) M355_LOAD(i)
@@ -741,6 +765,7 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
 #undef M355_NO_LOAD
 #undef M355_LOAD
 #undef M355_POINT_AT
+#undef M355_CODES_OF
 }
 
 // out[t][c] = sum over the token's local pairs, in k order.  FP16 mode rounds as the reference's fp16
@@ -824,7 +849,7 @@ static bool can_route_inline(int P, int E_local, int K) {
 template <int MODE, bool INLINE>
 static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, const MoeWorkspace& ws, int K, int R,
                        int k_top, int mt_rows, int slots, half_t* outp, int cus, hipStream_t st, const RouteIO& rio,
-                       const StageParams& sp) {
+                       const StageParams& sp, const uint8_t* wam8, const float* wtab) {
     const int NP = R / 32, NB = K / 64;
     if (NB <= MOE_KPARTS * MOE_CHUNK) {
         // upper bound of sum_e ceil(M_e / mt_rows): with T <= 16 a token tile holds a whole expert (M_e <= T = mt_rows)
@@ -835,20 +860,20 @@ static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, c
             const int lds = stream_lds_bytes(2, INLINE);
             const int grid = items2 < cus ? items2 : cus;
             moe_gemm_stream_kernel<MODE, 2, INLINE><<<dim3(grid), dim3(512), lds, st>>>(
-                xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio, sp);
+                xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio, sp, wam8, wtab);
         } else {
             const int lds = stream_lds_bytes(1, INLINE);
             const int per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
             const int items1 = max_tiles * NP;
             const int grid = items1 < per_cu * cus ? items1 : per_cu * cus;
             moe_gemm_stream_kernel<MODE, 1, INLINE><<<dim3(grid), dim3(256), lds, st>>>(
-                xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio, sp);
+                xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio, sp, wam8, wtab);
         }
         M355_LAUNCH_CHECK("moe_gemm_stream_kernel");
         return 0;
     }
-    if (sp.bias || sp.act_mode != M355_ACT_SILU_CONCAT)
-        return fail(-5, "m355_moe_nf4_forward: biases and swiglu-oai need K <= %d (K = %d)", 64 * MOE_KPARTS * MOE_CHUNK, K);
+    if (sp.bias || sp.act_mode != M355_ACT_SILU_CONCAT || wam8)
+        return fail(-5, "m355_moe_nf4_forward: biases, swiglu-oai and byte absmax need K <= %d (K = %d)", 64 * MOE_KPARTS * MOE_CHUNK, K);
     moe_gemm_kernel<MODE><<<dim3((NP + MOE_PAIRS - 1) / MOE_PAIRS, slots), dim3(MOE_THREADS), gemm_lds_bytes(K, mt_rows), st>>>(
         xin, wq, wam, ws.n_active, ws.offsets, ws.active, ws.sorted, K, R, k_top, mt_rows, outp);
     M355_LAUNCH_CHECK("moe_gemm_kernel");
@@ -872,14 +897,24 @@ extern "C" int m355_moe_nf4_forward(const void* x_f16, int T, const int32_t* ids
                                    flags, nullptr, nullptr, 1.702f, 7.0f, workspace, ws_bytes, out_f16, stream);
 }
 
-extern "C" int m355_moe_nf4_forward_ex(const void* x_f16, int T, const int32_t* ids, const float* w, int k,
-                                       const uint8_t* w13_q, const float* w13_absmax, const uint8_t* w2_q,
-                                       const float* w2_absmax, int E_local, int e_first, int H, int FF, int act_mode,
-                                       int flags, const void* b13_f16, const void* b2_f16, float alpha, float limit,
-                                       void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream) {
+// absmax of one weight matrix: fp32 per block, or the checkpoint's code byte per block + a 256-entry table per expert
+struct AbsmaxArg {
+    const float* f32;
+    const uint8_t* u8;
+    const float* table;
+    bool ok() const { return f32 ? true : (u8 && table); }
+    const void* base() const { return f32 ? (const void*)f32 : (const void*)u8; }
+};
+
+static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const float* w, int k, const uint8_t* w13_q,
+                            AbsmaxArg a13, const uint8_t* w2_q, AbsmaxArg a2, int E_local, int e_first, int H, int FF,
+                            int act_mode, int flags, const void* b13_f16, const void* b2_f16, float alpha, float limit,
+                            void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream) {
     if (T == 0) return 0;   // an empty batch has no buffers to check
-    if (!x_f16 || !ids || !w || !w13_q || !w13_absmax || !w2_q || !w2_absmax || !out_f16)
+    if (!x_f16 || !ids || !w || !w13_q || !a13.ok() || !w2_q || !a2.ok() || !out_f16)
         return fail(-1, "m355_moe_nf4_forward: null pointer");
+    const float* w13_absmax = a13.f32;
+    const float* w2_absmax = a2.f32;
     if (T < 0 || k <= 0 || k > 32 || E_local <= 0 || E_local > ROUTE_MAX_E || H <= 0 || FF <= 0 || (H % 64) || (FF % 64))
         return fail(-2, "m355_moe_nf4_forward: unsupported shape T=%d k=%d E_local=%d H=%d FF=%d (need H,FF %% 64 == 0, k <= 32, E_local <= %d)",
                     T, k, E_local, H, FF, ROUTE_MAX_E);
@@ -893,7 +928,8 @@ extern "C" int m355_moe_nf4_forward_ex(const void* x_f16, int T, const int32_t* 
     const size_t need = m355_moe_workspace_bytes(T, k, H, FF, E_local);
     if (!workspace || ws_bytes < need) return fail(-6, "m355_moe_nf4_forward: workspace of %zu bytes needed, %zu given", need, ws_bytes);
     if (!aligned(workspace, 256) || !aligned(x_f16, 16) || !aligned(out_f16, 16) || !aligned(w13_q, 16) || !aligned(w2_q, 16) ||
-        !aligned(w13_absmax, 16) || !aligned(w2_absmax, 16))
+        !aligned(a13.base(), 16) || !aligned(a2.base(), 16) || (a13.table && !aligned(a13.table, 16)) ||
+        (a2.table && !aligned(a2.table, 16)))
         return fail(-3, "m355_moe_nf4_forward: workspace 256-byte, other buffers 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const MoeWorkspace ws = carve_workspace(workspace, T, k, H, FF, E_local);
@@ -917,12 +953,12 @@ extern "C" int m355_moe_nf4_forward_ex(const void* x_f16, int T, const int32_t* 
         M355_LAUNCH_CHECK("moe_route_kernel");
     }
     if (!(flags & M355_FLAG_SKIP_GATE_UP)) {
-        if (int rc = inline_route ? launch_gemm<0, true>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13)
-                                  : launch_gemm<0, false>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13))
+        if (int rc = inline_route ? launch_gemm<0, true>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table)
+                                  : launch_gemm<0, false>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table))
             return rc;
     }
     if (!(flags & M355_FLAG_SKIP_DOWN)) {
-        if (int rc = launch_gemm<1, false>(ws.h, w2_q, w2_absmax, ws, FF, H, k, mt_rows, slots, ws.y, cus, st, rio, sp2)) return rc;
+        if (int rc = launch_gemm<1, false>(ws.h, w2_q, w2_absmax, ws, FF, H, k, mt_rows, slots, ws.y, cus, st, rio, sp2, a2.u8, a2.table)) return rc;
     }
     if (!(flags & M355_FLAG_SKIP_COMBINE)) {
         moe_combine_kernel<<<dim3(T), dim3(256), 0, st>>>(ws.y, ws.inv, w, H, k, (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0,
@@ -930,4 +966,26 @@ extern "C" int m355_moe_nf4_forward_ex(const void* x_f16, int T, const int32_t* 
         M355_LAUNCH_CHECK("moe_combine_kernel");
     }
     return 0;
+}
+
+extern "C" int m355_moe_nf4_forward_ex(const void* x_f16, int T, const int32_t* ids, const float* w, int k,
+                                       const uint8_t* w13_q, const float* w13_absmax, const uint8_t* w2_q,
+                                       const float* w2_absmax, int E_local, int e_first, int H, int FF, int act_mode,
+                                       int flags, const void* b13_f16, const void* b2_f16, float alpha, float limit,
+                                       void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream) {
+    return moe_forward_impl(x_f16, T, ids, w, k, w13_q, AbsmaxArg{w13_absmax, nullptr, nullptr}, w2_q,
+                            AbsmaxArg{w2_absmax, nullptr, nullptr}, E_local, e_first, H, FF, act_mode, flags, b13_f16, b2_f16,
+                            alpha, limit, workspace, ws_bytes, out_f16, stream);
+}
+
+extern "C" int m355_moe_nf4_forward_q8(const void* x_f16, int T, const int32_t* ids, const float* w, int k,
+                                       const uint8_t* w13_q, const uint8_t* w13_absmax_u8, const float* w13_table,
+                                       const uint8_t* w2_q, const uint8_t* w2_absmax_u8, const float* w2_table, int E_local,
+                                       int e_first, int H, int FF, int act_mode, int flags, const void* b13_f16,
+                                       const void* b2_f16, float alpha, float limit, void* workspace, size_t ws_bytes,
+                                       void* out_f16, m355_stream_t stream) {
+    if (T != 0 && (!w13_absmax_u8 || !w13_table || !w2_absmax_u8 || !w2_table)) return fail(-1, "m355_moe_nf4_forward_q8: null pointer");
+    return moe_forward_impl(x_f16, T, ids, w, k, w13_q, AbsmaxArg{nullptr, w13_absmax_u8, w13_table}, w2_q,
+                            AbsmaxArg{nullptr, w2_absmax_u8, w2_table}, E_local, e_first, H, FF, act_mode, flags, b13_f16, b2_f16,
+                            alpha, limit, workspace, ws_bytes, out_f16, stream);
 }

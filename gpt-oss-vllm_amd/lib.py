@@ -25,7 +25,7 @@ EXPORTS = (
     "m355_topk_softmax", "m355_moe_nf4_forward", "m355_moe_workspace_bytes", "m355_paged_attn_decode",
     "m355_paged_attn_workspace_bytes", "m355_ep_row_bytes", "m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce",
     "m355_add_rmsnorm", "m355_rope_kv_write", "m355_linear_f16", "m355_paged_attn_decode_ex",
-    "m355_repack_nf4_ex", "m355_moe_nf4_forward_ex",
+    "m355_repack_nf4_ex", "m355_moe_nf4_forward_ex", "m355_moe_nf4_forward_q8", "m355_repack_absmax_u8",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -55,6 +55,11 @@ def load() -> ctypes.CDLL:
     L.m355_moe_nf4_forward_ex.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
                                           vp, vp, f32, f32, vp, sz, vp, vp]
     L.m355_moe_nf4_forward_ex.restype = i32
+    L.m355_moe_nf4_forward_q8.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
+                                          vp, vp, f32, f32, vp, sz, vp, vp]
+    L.m355_moe_nf4_forward_q8.restype = i32
+    L.m355_repack_absmax_u8.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.m355_repack_absmax_u8.restype = i32
     L.m355_router_topk.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
     L.m355_topk_softmax.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     L.m355_moe_nf4_forward.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
@@ -167,7 +172,8 @@ def moe_nf4_forward(x, ids, w, w13_q, w13_absmax, w2_q, w2_absmax, *, E_local: i
                     b13: Optional[torch.Tensor] = None, b2: Optional[torch.Tensor] = None, alpha: float = 1.702,
                     limit: float = 7.0):
     """One MoE layer over this rank's experts (weights in tile order); optional per-expert biases b13 [E][2FF]
-    (gate entries then up entries), b2 [E][H].  m355_moe_nf4_forward_ex."""
+    (gate entries then up entries), b2 [E][H].  w13_absmax / w2_absmax are fp32 tensors, or (codes uint8, table fp32
+    [E][256]) pairs for the byte form.  m355_moe_nf4_forward_ex / m355_moe_nf4_forward_q8."""
     T, k = ids.shape
     need = moe_workspace_bytes(T, k, H, FF, E_local)
     if workspace is None:
@@ -178,6 +184,21 @@ def moe_nf4_forward(x, ids, w, w13_q, w13_absmax, w2_q, w2_absmax, *, E_local: i
         raise ValueError(f"b13 is {tuple(b13.shape)}, expected {(E_local, 2 * FF)}")
     if b2 is not None and tuple(b2.shape) != (E_local, H):
         raise ValueError(f"b2 is {tuple(b2.shape)}, expected {(E_local, H)}")
+    if isinstance(w13_absmax, tuple) != isinstance(w2_absmax, tuple):
+        raise ValueError("w13_absmax and w2_absmax must both be fp32 tensors or both (codes, table) pairs")
+    if isinstance(w13_absmax, tuple):
+        (c13, t13), (c2, t2) = w13_absmax, w2_absmax
+        if tuple(t13.shape) != (E_local, 256) or tuple(t2.shape) != (E_local, 256):
+            raise ValueError(f"absmax tables must be {(E_local, 256)}")
+        _check(load().m355_moe_nf4_forward_q8(
+            _dev(x, torch.float16, "x"), T, _dev(ids, torch.int32, "ids"), _dev(w, torch.float32, "w"), k,
+            _dev(w13_q, torch.uint8, "w13_q"), _dev(c13, torch.uint8, "w13_absmax codes"), _dev(t13, torch.float32, "w13 table"),
+            _dev(w2_q, torch.uint8, "w2_q"), _dev(c2, torch.uint8, "w2_absmax codes"), _dev(t2, torch.float32, "w2 table"),
+            E_local, e_first, H, FF, act_mode, flags, None if b13 is None else _dev(b13, torch.float16, "b13"),
+            None if b2 is None else _dev(b2, torch.float16, "b2"), float(alpha), float(limit),
+            _dev(workspace, torch.uint8, "workspace"), workspace.numel(), _dev(out, torch.float16, "out"), _stream()),
+            "m355_moe_nf4_forward_q8")
+        return out
     _check(load().m355_moe_nf4_forward_ex(
         _dev(x, torch.float16, "x"), T, _dev(ids, torch.int32, "ids"), _dev(w, torch.float32, "w"), k,
         _dev(w13_q, torch.uint8, "w13_q"), _dev(w13_absmax, torch.float32, "w13_absmax"),
@@ -299,4 +320,14 @@ def linear_f16(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
                                   None if bias is None else _dev(bias, torch.float16, "bias"), N, K,
                                   None if resid is None else _dev(resid, torch.float16, "resid"),
                                   _dev(out, torch.float16, "out"), _stream()), "m355_linear_f16")
+    return out
+
+
+def repack_absmax_u8(codes: torch.Tensor, rows: int, cols: int, row_order: int = 0):
+    """absmax code bytes of one expert matrix, checkpoint order -> tile order.  m355_repack_absmax_u8."""
+    if codes.numel() * 64 != rows * cols:
+        raise ValueError("repack_absmax_u8: sizes do not match rows*cols")
+    out = torch.empty_like(codes)
+    _check(load().m355_repack_absmax_u8(_dev(codes, torch.uint8, "codes"), rows, cols, int(row_order),
+                                        _dev(out, torch.uint8, "out"), _stream()), "m355_repack_absmax_u8")
     return out

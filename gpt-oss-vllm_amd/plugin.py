@@ -64,6 +64,30 @@ def resolve_absmax(absmax: Optional[torch.Tensor], nested_absmax: Optional[torch
     return absmax.detach().cpu().float()
 
 
+def resolve_absmax_table(absmax: Optional[torch.Tensor], nested_absmax: Optional[torch.Tensor],
+                         nested_quant_map: Optional[torch.Tensor]):
+    """(codes uint8 [nblk], table fp32 [256]) with table[codes] bit for bit resolve_absmax(...), or None when the
+    absmax is not one scalar times a 256-entry map (element-wise or broadcast nested scales, plain fp32 absmax).
+    Real checkpoints take the scalar branches (one nested scale per 256 blocks -> the mean fallback,
+    patches/streaming_unsloth_bnb.py:165-171), so their absmax can stay one byte per block on the GPU."""
+    if nested_absmax is None or nested_quant_map is None or absmax is None:
+        return None
+    na = nested_absmax.detach().cpu().float()
+    nm = nested_quant_map.detach().cpu().float().reshape(-1)
+    codes = absmax.detach().cpu().to(torch.uint8)
+    if nm.numel() != 256:
+        return None
+    if na.numel() == 1:
+        return codes.reshape(-1), nm * na.item()
+    if na.shape == codes.shape:
+        return None
+    try:
+        torch.broadcast_shapes(na.shape, codes.shape)
+        return None
+    except RuntimeError:
+        return codes.reshape(-1), nm * na.mean()
+
+
 # ---------------------------------------------------------------------------------------------
 # "true_bnb" layout: a tensor read the way bitsandbytes itself reads it, not the way the reference's loader does
 # ---------------------------------------------------------------------------------------------
@@ -112,8 +136,9 @@ class Mi355Nf4MoEConfig(_QConfigBase):
 
     LAYOUTS = ("reference", "true_bnb")
     GATE_UP_ORDERS = ("concat", "interleaved")
+    ABSMAX_STORAGE = ("auto", "fp32")
 
-    def __init__(self, layout: str = "reference", gate_up_order: str = "concat"):
+    def __init__(self, layout: str = "reference", gate_up_order: str = "concat", absmax_storage: str = "auto"):
         """layout "reference": tensors are read as the reference's loader reads them (low nibble first, mean
         fallback for the nested scales, no offset) -- the parity contract.  "true_bnb": as bitsandbytes wrote
         them (high nibble first, one nested scale per 256 blocks, plus nested_offset)."""
@@ -122,7 +147,12 @@ class Mi355Nf4MoEConfig(_QConfigBase):
             raise ValueError(f"layout {layout!r}: expected one of {self.LAYOUTS}")
         if gate_up_order not in self.GATE_UP_ORDERS:
             raise ValueError(f"gate_up_order {gate_up_order!r}: expected one of {self.GATE_UP_ORDERS}")
+        if absmax_storage not in self.ABSMAX_STORAGE:
+            raise ValueError(f"absmax_storage {absmax_storage!r}: expected one of {self.ABSMAX_STORAGE}")
         self.layout = layout
+        # "auto": a layer whose experts all resolve to (code byte, 256-entry table) keeps the absmax that way on the
+        # GPU (1 B instead of 4 B per 64 weights, same results bit for bit); "fp32": always one fp32 per block.
+        self.absmax_storage = absmax_storage
         # "concat": gate = rows [0, FF), up = rows [FF, 2FF) of gate_up, as the reference splits it
         # (patches/streaming_unsloth_bnb.py:269-270).  "interleaved": gate = even rows, up = odd rows, as gpt-oss
         # itself stores it (transformers models/gpt_oss/modeling_gpt_oss.py:80); goes with activation="swigluoai".
@@ -151,7 +181,8 @@ class Mi355Nf4MoEConfig(_QConfigBase):
     @classmethod
     def from_config(cls, config: Dict[str, Any]) -> "Mi355Nf4MoEConfig":
         config = config or {}
-        return cls(layout=config.get("layout", "reference"), gate_up_order=config.get("gate_up_order", "concat"))
+        return cls(layout=config.get("layout", "reference"), gate_up_order=config.get("gate_up_order", "concat"),
+                   absmax_storage=config.get("absmax_storage", "auto"))
 
     def get_scaled_act_names(self) -> List[str]:
         return []
@@ -257,6 +288,18 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
         dev = layer.w13_qweight.device
         if dev.type != "cuda":
             raise lib.Mi355LibraryError("expert weights must live on the GPU before process_weights_after_loading")
+        # byte absmax needs every expert of both matrices to resolve to (codes, table)
+        use_codes = (self.quant_config.absmax_storage == "auto" and self.quant_config.layout == "reference"
+                     and len(layer._m355_raw) == 2 * E
+                     and all(resolve_absmax_table(t.get("absmax"), t.get("nested_absmax"), t.get("nested_quant_map")) is not None
+                             for t in layer._m355_raw.values()))
+        if use_codes:
+            layer._m355_codes = {"w13": torch.empty((E, 2 * FF * H // BLOCKSIZE), dtype=torch.uint8, device=dev),
+                                 "w2": torch.empty((E, H * FF // BLOCKSIZE), dtype=torch.uint8, device=dev)}
+            layer._m355_tables = {"w13": torch.empty((E, 256), dtype=torch.float32, device=dev),
+                                  "w2": torch.empty((E, 256), dtype=torch.float32, device=dev)}
+        else:
+            layer._m355_codes = layer._m355_tables = None
         for (e, proj), t in sorted(layer._m355_raw.items()):
             if not (0 <= e < E) or "weight" not in t:
                 raise ValueError(f"incomplete or out-of-range expert tensor ({e}, {proj})")
@@ -288,6 +331,12 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
                 layer.w13_qweight.data[e], layer.w13_absmax.data[e] = qt, at
             else:
                 layer.w2_qweight.data[e], layer.w2_absmax.data[e] = qt, at
+            if use_codes:
+                codes, table = resolve_absmax_table(t.get("absmax"), t.get("nested_absmax"), t.get("nested_quant_map"))
+                tag = "w13" if proj == "gate_up_projs" else "w2"
+                layer._m355_codes[tag][e] = lib.repack_absmax_u8(codes.to(dev).contiguous(), rows, cols,
+                                                                 row_order=1 if interleaved else 0)
+                layer._m355_tables[tag][e] = table.to(dev)
         layer._m355_b13 = layer._m355_b2 = None
         b13 = layer._m355_bias.get("gate_up_proj_bias")
         if b13 is not None:
@@ -340,8 +389,12 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
         if ws is None:
             ws = torch.empty(max(256, lib.moe_workspace_bytes(T, top_k, H, FF, E)), dtype=torch.uint8, device=x2.device)
             layer._m355_ws = {T: ws}
-        out = lib.moe_nf4_forward(x2.contiguous(), ids, w, layer.w13_qweight.data, layer.w13_absmax.data,
-                                  layer.w2_qweight.data, layer.w2_absmax.data, E_local=E, e_first=e_first, H=H, FF=FF,
+        a13, a2 = layer.w13_absmax.data, layer.w2_absmax.data
+        if getattr(layer, "_m355_codes", None) is not None:
+            a13 = (layer._m355_codes["w13"], layer._m355_tables["w13"])
+            a2 = (layer._m355_codes["w2"], layer._m355_tables["w2"])
+        out = lib.moe_nf4_forward(x2.contiguous(), ids, w, layer.w13_qweight.data, a13,
+                                  layer.w2_qweight.data, a2, E_local=E, e_first=e_first, H=H, FF=FF,
                                   workspace=ws, act_mode=act_mode, b13=getattr(layer, "_m355_b13", None),
                                   b2=getattr(layer, "_m355_b2", None))
         if in_dtype != torch.float16:

@@ -113,6 +113,21 @@ M355_API int m355_moe_nf4_forward_ex(const void* x_f16, int T, const int32_t* id
                                      const float* w2_absmax, int E_local, int e_first, int H, int FF, int act_mode,
                                      int flags, const void* b13_f16, const void* b2_f16, float alpha, float limit,
                                      void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream);
+/* The same with the absmax kept as the checkpoint stores it: one code byte per 64-weight block (tile order of
+ * m355_repack_absmax_u8) and, per expert, a 256-entry fp32 table that maps a code to its absmax -- the
+ * `nested_quant_map[code] * scale` of patches/streaming_unsloth_bnb.py:150-171 with the scalar (the single
+ * nested_absmax, or its mean in the fallback real checkpoints take) multiplied in on the host, entry by entry, so
+ * table[code] is bit for bit the fp32 absmax the other entry points are handed.  0.52 instead of 0.56 bytes of HBM
+ * traffic per weight.  w13_table [E_local][256], w2_table [E_local][256]. */
+M355_API int m355_moe_nf4_forward_q8(const void* x_f16, int T, const int32_t* ids, const float* w, int k,
+                                     const uint8_t* w13_q, const uint8_t* w13_absmax_u8, const float* w13_table,
+                                     const uint8_t* w2_q, const uint8_t* w2_absmax_u8, const float* w2_table, int E_local,
+                                     int e_first, int H, int FF, int act_mode, int flags, const void* b13_f16,
+                                     const void* b2_f16, float alpha, float limit, void* workspace, size_t ws_bytes,
+                                     void* out_f16, m355_stream_t stream);
+/* absmax codes [rows*cols/64] bytes, checkpoint order -> the tile order of absmax_tiled in m355_repack_nf4. */
+M355_API int m355_repack_absmax_u8(const uint8_t* absmax_u8, int rows, int cols, int row_order, uint8_t* absmax_tiled,
+                                   m355_stream_t stream);
 M355_API size_t m355_moe_workspace_bytes(int T, int k, int H, int FF, int E_local);
 
 /*

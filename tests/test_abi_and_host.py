@@ -93,6 +93,13 @@ def test_host_absmax_resolution_equals_oracle(name, ref):
     got = plugin.resolve_absmax(t(c["absmax"]), t(c["nested_absmax"]), t(c["nested_map"])).numpy().astype(np.float32)
     want = ref.resolve_absmax(c["absmax"], c["nested_map"], c["nested_absmax"])
     assert np.array_equal(got.view(np.uint32).reshape(-1), want.view(np.uint32).reshape(-1))
+    # code byte + 256-entry table: only for the scalar / mean branches, and then the same bits entry by entry
+    ct = plugin.resolve_absmax_table(t(c["absmax"]), t(c["nested_absmax"]), t(c["nested_map"]))
+    assert (ct is not None) == (name in ("down_nested_mean", "down_nested_scalar"))
+    if ct is not None:
+        codes, table = ct
+        assert codes.dtype == torch.uint8 and tuple(table.shape) == (256,)
+        assert np.array_equal(table[codes.long()].numpy().view(np.uint32).reshape(-1), want.view(np.uint32).reshape(-1))
 
 
 def test_checkpoint_reader_schema(tmp_path, ref):

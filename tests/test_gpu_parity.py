@@ -335,6 +335,15 @@ def test_plugin_path_end_to_end(ref, m355, cuda, tmp_path):
     ids, w, _ = ref.router_topk(lg, np.eye(E, dtype=np.float16), None, k)
     want = ref.moe_forward(x, ids, w, **layer_ref, E_local=E, H=H, FF=FF)
     _close(out.cpu().numpy(), want)
+    # these tensors resolve to code byte + table, so the layer keeps the absmax as bytes; fp32 storage gives the same bits
+    assert layer._m355_codes is not None
+    method32 = plugin.Mi355Nf4MoEConfig(absmax_storage="fp32").get_quant_method(None, "model.layers.2.mlp.experts")
+    layer32 = torch.nn.Module()
+    method32.create_weights(layer32, E, H, FF, torch.float16, device=cuda)
+    checkpoint.load_layer(method32, layer32, [shard], 2)
+    assert layer32._m355_codes is None
+    out32 = method32.apply(layer32, _to_dev(x, cuda), _to_dev(lg, cuda), top_k=k, renormalize=True)
+    assert torch.equal(out32, out)
     # bf16 activations are accepted (converted at the boundary) and come back as bf16
     out_bf = method.apply(layer, _to_dev(x, cuda).to(torch.bfloat16), _to_dev(lg, cuda), top_k=k, renormalize=True)
     assert out_bf.dtype == torch.bfloat16
@@ -356,3 +365,41 @@ def test_expert_parallel_class_single_rank(ref, m355, cuda):
     _close(out.cpu().numpy(), want)
     with pytest.raises(ValueError):
         moe.forward(_to_dev(x[:2], cuda), _to_dev(ids[:2], cuda), _to_dev(w[:2], cuda))
+
+
+@pytest.mark.parametrize("T,E,k,H,FF,act", [(32, 32, 4, 2880, 2880, "silu"), (1, 32, 4, 2880, 2880, "silu"),
+                                            (19, 8, 3, 256, 192, "oai"), (70, 4, 2, 256, 192, "silu")])
+def test_moe_forward_byte_absmax_equals_fp32_absmax(T, E, k, H, FF, act, ref, m355, cuda):
+    """absmax kept as the checkpoint's code byte + a 256-entry table per expert (m355_moe_nf4_forward_q8) gives the
+    bits of the fp32-absmax entry point when table[code] is that fp32 absmax (the reference's
+    nested_quant_map[code] * scalar, patches/streaming_unsloth_bnb.py:150-171)."""
+    sd = ref.stream_seed(T, E, k, 4321)
+    nm = ref.nested_quant_map()
+    q13 = np.stack([ref.fill_bytes(ref.stream_seed(sd, e, 1), FF * H) for e in range(E)])
+    q2 = np.stack([ref.fill_bytes(ref.stream_seed(sd, e, 2), H * FF // 2) for e in range(E)])
+    c13 = np.stack([ref.fill_bytes(ref.stream_seed(sd, e, 3), 2 * FF * H // 64) for e in range(E)])
+    c2 = np.stack([ref.fill_bytes(ref.stream_seed(sd, e, 4), H * FF // 64) for e in range(E)])
+    scale = (0.01 + 0.02 * ref.uniform01(ref.stream_seed(sd, 5), 2 * E)).astype(np.float32)
+    t13 = (nm[None, :] * scale[:E, None]).astype(np.float32)
+    t2 = (nm[None, :] * scale[E:, None]).astype(np.float32)
+    layer = dict(w13_q=q13, w13_absmax=np.stack([t13[e][c13[e]] for e in range(E)]),
+                 w2_q=q2, w2_absmax=np.stack([t2[e][c2[e]] for e in range(E)]))
+    w13_q, w13_a, w2_q, w2_a = tiled_layer(m355, layer, E, H, FF, cuda)
+    c13_t = torch.stack([m355.repack_absmax_u8(_to_dev(c13[e], cuda), 2 * FF, H) for e in range(E)])
+    c2_t = torch.stack([m355.repack_absmax_u8(_to_dev(c2[e], cuda), H, FF) for e in range(E)])
+    x = _to_dev(ref.normal_f16(ref.stream_seed(sd, 6), (T, H)), cuda)
+    lg = ref.normal_f16(ref.stream_seed(sd, 7), (T, E), 1.5)
+    ids, w = m355.topk_softmax(_to_dev(lg, cuda), k)
+    kw = dict(E_local=E, e_first=0, H=H, FF=FF)
+    if act == "oai":
+        kw.update(act_mode=m355.ACT_SWIGLU_OAI,
+                  b13=_to_dev(ref.normal_f16(ref.stream_seed(sd, 8), (E, 2 * FF), 0.1), cuda),
+                  b2=_to_dev(ref.normal_f16(ref.stream_seed(sd, 9), (E, H), 0.1), cuda))
+    want = m355.moe_nf4_forward(x, ids, w, w13_q, w13_a, w2_q, w2_a, **kw)
+    got = m355.moe_nf4_forward(x, ids, w, w13_q, (c13_t, _to_dev(t13, cuda)), w2_q, (c2_t, _to_dev(t2, cuda)), **kw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(want.float()).all() and want.float().abs().max() > 0
+    assert torch.equal(got, want)
+    if T <= 32 and H == 2880:
+        ref_out = ref.moe_forward(x.cpu().numpy(), ids.cpu().numpy(), w.cpu().numpy(), **layer, E_local=E, H=H, FF=FF)
+        _close(got.cpu().numpy(), ref_out)
