@@ -20,7 +20,7 @@
 // Dequantisation: a byte holds two codes; a 256-entry table of packed half2 (code[lo], code[hi]) is
 // replicated 32x in LDS (entry address = (byte*32 + lane%32)*4) so a wave's lookups never collide on a bank.
 // The code values are fp16-rounded NF4 entries; scales stay fp32.
-#include "common.h"
+#include "moe_shared.h"
 
 namespace m355 {
 
@@ -32,43 +32,6 @@ constexpr int LUT_BYTES = 256 * 32 * 4;
 constexpr int RED_BYTES = MOE_PAIRS * (MOE_KPARTS - 1) * 64 * 8 * 4;
 constexpr int XS_PAD = 16;        // bytes of padding per staged activation row
 constexpr int MOE_MAX_MT = 16;
-
-__host__ __device__ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-struct MoeWorkspace {
-    int32_t* n_active;   // [1]
-    int32_t* offsets;    // [E_local + 1]
-    int32_t* active;     // [E_local]
-    int32_t* sorted;     // [P]   sorted position -> pair index (t*k + kk)
-    int32_t* inv;        // [P]   pair index -> sorted position, -1 if the expert is not local
-    int32_t* n_tiles;    // [1]   token tiles (<= mt_rows tokens of one expert) over all active experts
-    int32_t* tile_expert;  // [P + E_local]
-    int32_t* tile_m0;      // [P + E_local]  first token (within the expert) of the tile
-    half_t* h;           // [P][FF]
-    half_t* y;           // [P][H]
-    size_t bytes;
-    int max_pairs;       // P
-};
-
-__host__ inline MoeWorkspace carve_workspace(void* base, int T, int k, int H, int FF, int E_local) {
-    const size_t P = (size_t)T * k;
-    size_t off = 0;
-    char* b = reinterpret_cast<char*>(base);
-    MoeWorkspace w;
-    w.n_active = reinterpret_cast<int32_t*>(b + off); off = align_up(off + 4, 256);
-    w.offsets = reinterpret_cast<int32_t*>(b + off);  off = align_up(off + 4 * (size_t)(E_local + 1), 256);
-    w.active = reinterpret_cast<int32_t*>(b + off);   off = align_up(off + 4 * (size_t)E_local, 256);
-    w.sorted = reinterpret_cast<int32_t*>(b + off);   off = align_up(off + 4 * P, 256);
-    w.inv = reinterpret_cast<int32_t*>(b + off);      off = align_up(off + 4 * P, 256);
-    w.n_tiles = reinterpret_cast<int32_t*>(b + off);  off = align_up(off + 4, 256);
-    w.tile_expert = reinterpret_cast<int32_t*>(b + off); off = align_up(off + 4 * (P + (size_t)E_local), 256);
-    w.tile_m0 = reinterpret_cast<int32_t*>(b + off);  off = align_up(off + 4 * (P + (size_t)E_local), 256);
-    w.h = reinterpret_cast<half_t*>(b + off);         off = align_up(off + 2 * P * FF, 256);
-    w.y = reinterpret_cast<half_t*>(b + off);         off = align_up(off + 2 * P * H, 256);
-    w.bytes = off;
-    w.max_pairs = (int)P;
-    return w;
-}
 
 // ------------------------------------------------------------------------------------------------
 // Routing: one workgroup buckets the pairs by local expert.
@@ -356,14 +319,6 @@ __global__ __launch_bounds__(MOE_THREADS) void moe_gemm_kernel(const half_t* __r
 // also wait for the prefetch.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// Activation and bias of one GEMM stage.  bias: [E_local][R] fp16 in the kernel's row order (gate rows, then up rows),
-// or null.
-struct StageParams {
-    int act_mode;            // M355_ACT_* (gate_up stage only)
-    float alpha, limit;      // swiglu-oai
-    const half_t* bias;
-};
 
 // Write one lane's 4 rows of both tiles for token row `orow`: h = act(gate, up) (MODE 0) or y (MODE 1), expert e.
 template <int MODE>
@@ -835,6 +790,18 @@ static int device_setup(int dev, int* cus) {
     return 0;
 }
 
+static int tile_gemm_device_setup_once(int dev) {
+    static bool done[64] = {false};
+    if (!done[dev & 63]) {
+        if (int rc = tile_gemm_device_setup()) return rc;
+        done[dev & 63] = true;
+    }
+    return 0;
+}
+
+// mean (token, k) pairs per local expert from which the tile kernel takes over
+constexpr int TILE_MIN_MEAN_PAIRS = 24;
+
 static int stream_lds_bytes(int pairs, bool inline_route) {   // (activations live in registers)
     return LUTP_BYTES + 2 * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4 + (inline_route ? (int)align_up(sizeof(InlineTables), 16) : 0);
 }
@@ -934,17 +901,24 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
     hipStream_t st = (hipStream_t)stream;
     const MoeWorkspace ws = carve_workspace(workspace, T, k, H, FF, E_local);
     const int P = T * k;
-    const int mt_rows = T < MOE_MAX_MT ? T : MOE_MAX_MT;
+    // Two kernels.  Few tokens per expert: the streaming kernel (HBM-bound; a token tile holds <= 16 tokens and every
+    // tile streams its expert's weights).  Many: the tile kernel (256-token tiles, weights dequantised once per tile).
+    // The choice is made on the host from the mean pairs per local expert, so that no routing result has to be read
+    // back; the flags force either.
+    bool tiled = T > MOE_MAX_MT && (int64_t)P >= (int64_t)TILE_MIN_MEAN_PAIRS * E_local;
+    if (flags & M355_FLAG_FORCE_TILE) tiled = true;
+    if (flags & M355_FLAG_FORCE_STREAM) tiled = false;
+    const int mt_rows = tiled ? TILE_ROWS : (T < MOE_MAX_MT ? T : MOE_MAX_MT);
     const int slots = P < E_local ? P : E_local;
 
     int dev = 0, cus = 0;
     if (int rc = hip_status(hipGetDevice(&dev), "hipGetDevice")) return rc;
     if (int rc = device_setup(dev, &cus)) return rc;
-    if (gemm_lds_bytes(H, mt_rows) > 160 * 1024 || gemm_lds_bytes(FF, mt_rows) > 160 * 1024)
+    if (!tiled && (gemm_lds_bytes(H, mt_rows) > 160 * 1024 || gemm_lds_bytes(FF, mt_rows) > 160 * 1024))
         return fail(-2, "m355_moe_nf4_forward: H or FF too large for the LDS activation tile");
 
     // gate_up buckets the pairs itself when it can; the routing kernel runs when it cannot, or when gate_up is skipped
-    const bool inline_route = can_route_inline(P, E_local, H) && !(flags & M355_FLAG_SKIP_GATE_UP);
+    const bool inline_route = !tiled && can_route_inline(P, E_local, H) && !(flags & M355_FLAG_SKIP_GATE_UP);
     const RouteIO rio = {ids, P, E_local, e_first, ws.n_active, ws.offsets, ws.active, ws.sorted, ws.inv, ws.n_tiles, ws.tile_expert, ws.tile_m0};
     if (!(flags & M355_FLAG_SKIP_ROUTE) && !inline_route) {
         moe_route_kernel<<<dim3(1), dim3(ROUTE_THREADS), 0, st>>>(ids, P, E_local, e_first, ws.n_active, ws.offsets,
@@ -952,12 +926,23 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
                                                                   ws.tile_expert, ws.tile_m0);
         M355_LAUNCH_CHECK("moe_route_kernel");
     }
-    if (!(flags & M355_FLAG_SKIP_GATE_UP)) {
+    if (tiled) {
+        if (int rc = tile_gemm_device_setup_once(dev)) return rc;
+        const int max_tiles = (slots + P / TILE_ROWS < P) ? slots + P / TILE_ROWS : P;   // >= sum_e ceil(M_e / TILE_ROWS)
+        if (!(flags & M355_FLAG_SKIP_GATE_UP))
+            if (int rc = launch_tile_gemm(0, (const half_t*)x_f16, w13_q, w13_absmax, a13.u8, a13.table, ws, H, 2 * FF, k,
+                                          max_tiles, ws.h, sp13, st))
+                return rc;
+        if (!(flags & M355_FLAG_SKIP_DOWN))
+            if (int rc = launch_tile_gemm(1, ws.h, w2_q, w2_absmax, a2.u8, a2.table, ws, FF, H, k, max_tiles, ws.y, sp2, st))
+                return rc;
+    }
+    if (!tiled && !(flags & M355_FLAG_SKIP_GATE_UP)) {
         if (int rc = inline_route ? launch_gemm<0, true>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table)
                                   : launch_gemm<0, false>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table))
             return rc;
     }
-    if (!(flags & M355_FLAG_SKIP_DOWN)) {
+    if (!tiled && !(flags & M355_FLAG_SKIP_DOWN)) {
         if (int rc = launch_gemm<1, false>(ws.h, w2_q, w2_absmax, ws, FF, H, k, mt_rows, slots, ws.y, cus, st, rio, sp2, a2.u8, a2.table)) return rc;
     }
     if (!(flags & M355_FLAG_SKIP_COMBINE)) {

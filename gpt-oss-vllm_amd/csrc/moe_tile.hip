@@ -1,0 +1,233 @@
+// Fused NF4-dequant grouped GEMM for many tokens per expert (prefill, large decode batches): MFMA-bound.
+//
+// A workgroup owns up to 256 tokens of one expert (a token tile) times 256 weight rows (8 row-tile pairs of the tile
+// order that m355_repack_nf4 writes, one pair = 32 rows per wave) and walks K in 64-column blocks, the NF4 absmax
+// block.  Per block:
+//   * each wave fetches its own packed KiB (one global_load_dwordx4 per lane, prefetched one block ahead), turns it
+//     into the A fragments of four v_mfma_f32_32x32x16_f16 (rows = 16 rows of the pair's first tile + the 16 partner
+//     rows) and reuses them for every token of the tile: the weights never pass through LDS and are dequantised once
+//     per 256 tokens.  w = fp16(code * absmax) with the product in fp32, which is bit for bit the weight the
+//     reference's dequantiser produces (patches/streaming_unsloth_bnb.py:192-222);
+//   * the activations of the token tile (256 x 64 fp16 = 32 KiB) are shared by the 8 waves: LDS-DMA
+//     (global_load_lds_dwordx4) in whole 128-byte lines into one of two buffers, 16-byte chunks XOR-swizzled on the
+//     source side so that the ds_read_b128 of the B fragments is bank-conflict free.
+// Lane l of a wave = (r = l & 15, s = (l >> 4) & 1, h = l >> 5).  As loaded, lane (r, g = s + 2h) holds 16 codes of
+// row r and 16 of its partner row, columns 16g..16g+15.  One v_permlane16_swap per dword pair trades the partner-row
+// half of the s = 0 lanes against the first-row half of the s = 1 lanes, after which lane (r, s, h) holds row
+// (s, r), columns 32h..32h+31 of the block: MFMA step t (K = 16) takes columns 32h + 8t.. from lane half h.
+#include "moe_shared.h"
+
+namespace m355 {
+
+typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+constexpr int TG_WAVES = 8;
+constexpr int TG_THREADS = TG_WAVES * 64;
+constexpr int TG_LUT_BYTES = 256 * 256;          // float2 per byte value, 32 replicas of 8 B in a 256-byte row
+constexpr int TG_XBUF = TILE_ROWS * 128;         // one activation buffer: 256 tokens x 64 columns fp16
+constexpr int TG_LDS = TG_LUT_BYTES + 2 * TG_XBUF;
+constexpr int TG_TOKEN_TILES = TILE_ROWS / 32;   // 32-token MFMA tiles per token tile
+
+static __device__ const float nf4_codes[16] = M355_NF4_TABLE;
+
+typedef const float2_t __attribute__((address_space(3))) lds_f2_t;
+typedef const half8_t __attribute__((address_space(3))) lds_h8_t;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// 8 weights of one packed dword: four table lookups (address = one v_perm_b32: byte k of d above the lane's replica
+// offset), scaled in fp32, rounded to fp16 (round to nearest even).
+__device__ __forceinline__ half8_t dequant8(uint32_t lbase, uint32_t d, float s) {
+    uint32_t a0 = __builtin_amdgcn_perm(d, lbase, 0x03020400u), a1 = __builtin_amdgcn_perm(d, lbase, 0x03020500u);
+    uint32_t a2 = __builtin_amdgcn_perm(d, lbase, 0x03020600u), a3 = __builtin_amdgcn_perm(d, lbase, 0x03020700u);
+    const float2_t f0 = *reinterpret_cast<lds_f2_t*>(a0), f1 = *reinterpret_cast<lds_f2_t*>(a1);
+    const float2_t f2 = *reinterpret_cast<lds_f2_t*>(a2), f3 = *reinterpret_cast<lds_f2_t*>(a3);
+    const half2_t h0 = __builtin_convertvector(f0 * s, half2_t), h1 = __builtin_convertvector(f1 * s, half2_t);
+    const half2_t h2 = __builtin_convertvector(f2 * s, half2_t), h3 = __builtin_convertvector(f3 * s, half2_t);
+    return half8_t{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+}
+
+__device__ __forceinline__ float act_pair(float gate_acc, float up_acc, const StageParams& sp) {
+    if (sp.act_mode == M355_ACT_SWIGLU_OAI) {
+        const float gt = fminf((float)(half_t)gate_acc, sp.limit);   // gate and up leave the GEMM as fp16
+        const float up = fminf(fmaxf((float)(half_t)up_acc, -sp.limit), sp.limit);
+        const float glu = gt / (1.0f + expf(-sp.alpha * gt));
+        return (up + 1.0f) * glu;
+    }
+    const float gt = (float)(half_t)gate_acc;
+    const float up = (float)(half_t)up_acc;
+    const half_t sg = (half_t)(gt / (1.0f + expf(-gt)));
+    return (float)sg * up;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
+    const half_t* __restrict__ xin, const uint8_t* __restrict__ wq, const float* __restrict__ wam,
+    const uint8_t* __restrict__ wam8, const float* __restrict__ wtab, const int32_t* __restrict__ n_tiles,
+    const int32_t* __restrict__ tile_expert, const int32_t* __restrict__ tile_m0, const int32_t* __restrict__ offsets,
+    const int32_t* __restrict__ sorted, int K, int R, int k_top, half_t* __restrict__ outp, StageParams sp, int n_rg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // blocks of one token tile share blockIdx % 8 (one XCD's L2 under round-robin placement serves the tile's
+    // activations to all its row groups; placement affects speed only)
+    const int slot = blockIdx.x >> 3;
+    const int tt = (slot / n_rg) * 8 + (blockIdx.x & 7);
+    const int rg = slot - (slot / n_rg) * n_rg;
+    if (tt >= *n_tiles) return;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NB = K / 64, NP = R / 32;
+    const int e = tile_expert[tt];
+    const int pos0 = offsets[e] + tile_m0[tt];
+    const int mt = min(TILE_ROWS, offsets[e + 1] - pos0);
+    const int ntt = (mt + 31) >> 5;                         // live 32-token tiles
+    const int p = rg * TG_WAVES + wave;
+    const bool live = p < NP;
+    const int pc = live ? p : NP - 1;                       // idle waves run on a valid tile, results dropped
+    const int r = lane & 15, s = (lane >> 4) & 1, hh = lane >> 5, n32 = lane & 31;
+
+    // ---- activations: 4 LDS-DMA instructions per wave and block, each 8 tokens x 128 bytes ----
+    const half_t* xsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int m = 8 * (4 * wave + j) + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((m >> 1) & 7);
+        const int pos = pos0 + min(m, mt - 1);
+        const int64_t src_row = (MODE == 0) ? (int64_t)(sorted[pos] / k_top) : (int64_t)pos;
+        xsrc[j] = xin + src_row * K + chunk * 8;
+    }
+    auto stage_x = [&](int b, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (8 * (4 * wave + j) < mt)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(xsrc[j] + 64 * b),
+                                                 (lds_void_t*)(smem + TG_LUT_BYTES + buf * TG_XBUF + (4 * wave + j) * 1024), 16, 0, 0);
+        }
+    };
+    // B fragment of MFMA step t, token n32 of a 32-token tile: chunk 4h + t of the token's line
+    uint32_t boff[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) boff[t] = TG_LUT_BYTES + n32 * 128 + (((4 * hh + t) ^ ((n32 >> 1) & 7)) << 4);
+
+    // ---- weights ----
+    const size_t wq_expert = (size_t)R * K / 2, am_expert = (size_t)R * NB;
+    const u32x4_t* wptr = reinterpret_cast<const u32x4_t*>(wq + (size_t)e * wq_expert + (size_t)pc * NB * 1024) + lane;
+    const size_t am_idx = (((size_t)(pc * 2 + s) * 4 + (r >> 2)) * NB) * 4 + (r & 3);   // + 4 per block
+    const float* amf = wam ? wam + (size_t)e * am_expert + am_idx : nullptr;
+    const uint8_t* am8 = wam8 ? wam8 + (size_t)e * am_expert + am_idx : nullptr;
+    const float* tab = wam8 ? wtab + (size_t)e * 256 : nullptr;
+    auto load_scale = [&](int b) -> float { return am8 ? tab[am8[4 * b]] : amf[4 * b]; };
+
+    stage_x(0, 0);
+    u32x4_t wreg = __builtin_nontemporal_load(wptr);
+    float sreg = load_scale(0);
+
+    // code table: entry (byte v, replica) = (code[v & 15], code[v >> 4]) as two fp32
+    for (int i = tid; i < 256 * 32; i += TG_THREADS) {
+        const int v = i >> 5;
+        *reinterpret_cast<float2_t*>(smem + v * 256 + (i & 31) * 8) = float2_t{nf4_codes[v & 15], nf4_codes[v >> 4]};
+    }
+    const uint32_t lbase = (uint32_t)(n32 * 8);   // the table starts at LDS address 0 (no static LDS in this kernel)
+
+    float16_t acc[TG_TOKEN_TILES];
+#pragma unroll
+    for (int c = 0; c < TG_TOKEN_TILES; c++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[c][i] = 0.f;
+
+    for (int b = 0; b < NB; b++) {
+        // block b's activations have landed (every wave's DMA), and every wave is done reading the other buffer
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // rows: trade halves so that this lane holds 32 columns of one row (see the header comment)
+        const auto sw0 = __builtin_amdgcn_permlane16_swap(wreg[0], wreg[2], false, false);
+        const auto sw1 = __builtin_amdgcn_permlane16_swap(wreg[1], wreg[3], false, false);
+        half8_t af[4];
+        af[0] = dequant8(lbase, sw0[0], sreg);
+        af[1] = dequant8(lbase, sw1[0], sreg);
+        af[2] = dequant8(lbase, sw0[1], sreg);
+        af[3] = dequant8(lbase, sw1[1], sreg);
+        if (b + 1 < NB) {
+            stage_x(b + 1, (b + 1) & 1);
+            wreg = __builtin_nontemporal_load(wptr + (size_t)(b + 1) * 64);
+            sreg = load_scale(b + 1);
+        }
+        const uint32_t xb = (uint32_t)((b & 1) * TG_XBUF);
+#pragma unroll
+        for (int c = 0; c < TG_TOKEN_TILES; c++) {
+            if (c < ntt) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const half8_t bf = *reinterpret_cast<lds_h8_t*>(boff[t] + xb + (uint32_t)(c * 4096));
+                    acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], bf, acc[c], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: accumulator register i of lane (n32, h) is token n32, row (i & 3) + 8 (i >> 2) + 4h of the
+    // 32-row tile; rows 0..15 are the pair's first tile (16p + ..), rows 16..31 its partner (16 (p + NP) + ..)
+    if (!live) return;
+    float ba[8], bb[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        ba[i] = sp.bias ? (float)sp.bias[(int64_t)e * R + 16 * p + row] : 0.f;
+        bb[i] = sp.bias ? (float)sp.bias[(int64_t)e * R + 16 * (p + NP) + row] : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < TG_TOKEN_TILES; c++) {
+        const int m = 32 * c + n32;
+        if (m < mt) {
+            const int64_t orow = pos0 + m;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {   // rows 4h.. and 8 + 4h..
+                half4_t va, vb;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float a = acc[c][4 * q + i] + ba[4 * q + i], bq = acc[c][8 + 4 * q + i] + bb[4 * q + i];
+                    if (MODE == 0) {
+                        va[i] = (half_t)act_pair(a, bq, sp);
+                    } else {
+                        va[i] = (half_t)a;
+                        vb[i] = (half_t)bq;
+                    }
+                }
+                if (MODE == 0) {
+                    *reinterpret_cast<half4_t*>(outp + orow * (R / 2) + 16 * p + 8 * q + 4 * hh) = va;
+                } else {
+                    *reinterpret_cast<half4_t*>(outp + orow * R + 16 * p + 8 * q + 4 * hh) = va;
+                    *reinterpret_cast<half4_t*>(outp + orow * R + 16 * (p + NP) + 8 * q + 4 * hh) = vb;
+                }
+            }
+        }
+    }
+}
+
+int tile_gemm_device_setup() {
+    if (int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_tile_gemm_kernel<0>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, TG_LDS), "hipFuncSetAttribute"))
+        return rc;
+    return hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(&moe_tile_gemm_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, TG_LDS), "hipFuncSetAttribute");
+}
+
+int launch_tile_gemm(int mode, const half_t* xin, const uint8_t* wq, const float* wam, const uint8_t* wam8,
+                     const float* wtab, const MoeWorkspace& ws, int K, int R, int k_top, int max_tiles, half_t* outp,
+                     const StageParams& sp, hipStream_t st) {
+    const int NP = R / 32;
+    const int n_rg = (NP + TG_WAVES - 1) / TG_WAVES;
+    const int64_t blocks = (int64_t)8 * ((max_tiles + 7) / 8) * n_rg;
+    if (blocks <= 0 || blocks > 0x7fffffff) return fail(-2, "m355_moe_nf4_forward: %lld workgroups", (long long)blocks);
+    if (mode == 0)
+        moe_tile_gemm_kernel<0><<<dim3((unsigned)blocks), dim3(TG_THREADS), TG_LDS, st>>>(
+            xin, wq, wam, wam8, wtab, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, outp, sp, n_rg);
+    else
+        moe_tile_gemm_kernel<1><<<dim3((unsigned)blocks), dim3(TG_THREADS), TG_LDS, st>>>(
+            xin, wq, wam, wam8, wtab, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, outp, sp, n_rg);
+    M355_LAUNCH_CHECK("moe_tile_gemm_kernel");
+    return 0;
+}
+
+}  // namespace m355

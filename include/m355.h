@@ -41,6 +41,11 @@ typedef void* m355_stream_t; /* a hipStream_t (NULL = the default stream) */
 #define M355_FLAG_SKIP_GATE_UP 0x200
 #define M355_FLAG_SKIP_DOWN 0x400
 #define M355_FLAG_SKIP_COMBINE 0x800
+/* Kernel choice, normally made from the mean number of (token, k) pairs per local expert: FORCE_STREAM = the
+   HBM-bound kernel for few tokens per expert (token tiles of <= 16), FORCE_TILE = the MFMA-bound kernel for many
+   (token tiles of 256, weights dequantised once per tile).  Both compute the same layer. */
+#define M355_FLAG_FORCE_STREAM 0x1000
+#define M355_FLAG_FORCE_TILE 0x2000
 
 M355_API int m355_version(void);
 M355_API const char* m355_last_error(void);

@@ -403,3 +403,98 @@ def test_moe_forward_byte_absmax_equals_fp32_absmax(T, E, k, H, FF, act, ref, m3
     if T <= 32 and H == 2880:
         ref_out = ref.moe_forward(x.cpu().numpy(), ids.cpu().numpy(), w.cpu().numpy(), **layer, E_local=E, H=H, FF=FF)
         _close(got.cpu().numpy(), ref_out)
+
+
+# ------------------------------------------------------------------------------------------------
+# The kernel for many tokens per expert (256-token tiles, M355_FLAG_FORCE_TILE) against the oracle and against the
+# kernel for few tokens per expert on the same inputs.
+@pytest.mark.parametrize("T,E,k,H,FF,act", [(40, 4, 2, 256, 192, "silu"), (300, 4, 2, 256, 192, "oai"),
+                                            (700, 2, 2, 256, 192, "silu"), (33, 40, 4, 256, 192, "silu"),
+                                            (96, 4, 2, 2880, 2880, "silu"), (70, 4, 2, 2880, 2880, "oai")])
+def test_moe_tile_kernel_vs_oracle_and_stream_kernel(T, E, k, H, FF, act, ref, m355, cuda):
+    sd = ref.stream_seed(T, E, k, 2025)
+    layer = ref.synth_layer(sd, E, H, FF)
+    x = ref.normal_f16(ref.stream_seed(sd, 1), (T, H))
+    lg = ref.normal_f16(ref.stream_seed(sd, 2), (T, E), 1.5)
+    ids, w = m355.topk_softmax(_to_dev(lg, cuda), k)
+    tl = tiled_layer(m355, layer, E, H, FF, cuda)
+    xd = _to_dev(x, cuda)
+    kw = dict(E_local=E, e_first=0, H=H, FF=FF)
+    b13 = b2 = None
+    if act == "oai":
+        b13 = ref.normal_f16(ref.stream_seed(sd, 8), (E, 2 * FF), 0.1)
+        b2 = ref.normal_f16(ref.stream_seed(sd, 9), (E, H), 0.1)
+        kw.update(act_mode=m355.ACT_SWIGLU_OAI, b13=_to_dev(b13, cuda), b2=_to_dev(b2, cuda))
+    F = m355.FLAG_FP16_COMBINE
+    tile = m355.moe_nf4_forward(xd, ids, w, *tl, flags=F | m355.FLAG_FORCE_TILE, **kw)
+    stream = m355.moe_nf4_forward(xd, ids, w, *tl, flags=F | m355.FLAG_FORCE_STREAM, **kw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(tile.float()).all()
+    _close(tile.cpu().numpy(), stream.cpu().numpy())
+    ids_h, w_h = ids.cpu().numpy(), w.cpu().numpy()
+    if act == "oai":
+        w13 = np.stack([ref.nf4_dequant(layer["w13_q"][e], 2 * FF * H, layer["w13_absmax"][e]).reshape(2 * FF, H) for e in range(E)])
+        w2 = np.stack([ref.nf4_dequant(layer["w2_q"][e], H * FF, layer["w2_absmax"][e]).reshape(H, FF) for e in range(E)])
+        # the kernels' row order is gate rows then up rows; the gpt-oss oracle takes them interleaved
+        w13_il = np.empty_like(w13)
+        w13_il[:, 0::2], w13_il[:, 1::2] = w13[:, :FF], w13[:, FF:]
+        b13_il = np.empty_like(b13)
+        b13_il[:, 0::2], b13_il[:, 1::2] = b13[:, :FF], b13[:, FF:]
+        want = ref.moe_forward_oai(x, ids_h, w_h, w13_il, w2, b13_il, b2)
+        _close(tile.cpu().numpy(), want, rtol=5e-3)
+    else:
+        want = ref.moe_forward(x, ids_h, w_h, **layer, E_local=E, H=H, FF=FF)
+        _close(tile.cpu().numpy(), want)
+
+
+def test_moe_tile_kernel_prefill_size(ref, m355, cuda):
+    """4096 tokens through 32 full-size experts (about 512 per expert: two 256-token tiles each, the kernel is chosen
+    from the shape, no flag): sampled tokens against the oracle (a token's output depends on no other token),
+    byte absmax against fp32 absmax bit for bit, and linearity in the routing weights."""
+    T, E, k, H, FF = 4096, 32, 4, 2880, 2880
+    g = torch.Generator(device=cuda)
+    g.manual_seed(99)
+    nm = ref.nested_quant_map()
+    q13 = torch.randint(0, 256, (E, FF * H), dtype=torch.uint8, device=cuda, generator=g)
+    q2 = torch.randint(0, 256, (E, H * FF // 2), dtype=torch.uint8, device=cuda, generator=g)
+    c13 = torch.randint(0, 256, (E, 2 * FF * H // 64), dtype=torch.uint8, device=cuda, generator=g)
+    c2 = torch.randint(0, 256, (E, H * FF // 64), dtype=torch.uint8, device=cuda, generator=g)
+    t13 = (torch.from_numpy(nm)[None, :] * (0.01 + 0.02 * torch.rand((E, 1)))).float().to(cuda)
+    t2 = (torch.from_numpy(nm)[None, :] * (0.01 + 0.02 * torch.rand((E, 1)))).float().to(cuda)
+    a13, a2 = torch.gather(t13, 1, c13.long()), torch.gather(t2, 1, c2.long())
+    x = torch.randn((T, H), device=cuda, generator=g).half()
+    lg = (torch.randn((T, E), device=cuda, generator=g) * 1.5).half()
+    ids, w = m355.topk_softmax(lg, k)
+    kw = dict(E_local=E, e_first=0, H=H, FF=FF)
+    out = m355.moe_nf4_forward(x, ids, w, q13, a13, q2, a2, flags=0, **kw)
+    out8 = m355.moe_nf4_forward(x, ids, w, q13, (c13, t13), q2, (c2, t2), flags=0, **kw)
+    out2 = m355.moe_nf4_forward(x, ids, 2 * w, q13, a13, q2, a2, flags=0, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out8)
+    _close(out2.float().cpu().numpy(), 2 * out.float().cpu().numpy(), rtol=1e-3)
+    # oracle on 6 sampled tokens; the tensors here are already in tile order, so undo it on the host for the experts used
+    sample = [0, 255, 256, 1777, 4000, 4095]
+    ids_h, w_h = ids.cpu().numpy(), w.cpu().numpy()
+    used = sorted({int(e) for t in sample for e in ids_h[t]})
+    remap = {e: i for i, e in enumerate(used)}
+
+    def untile(qt, at, rows, cols):
+        """inverse of m355_repack_nf4 for one expert (host)."""
+        NB, P = cols // 64, rows // 32
+        qt = qt.reshape(P, NB, 4, 16, 2, 8)                       # [p][b][g][r][half][8 bytes]
+        q = np.empty((rows, cols // 2), np.uint8).reshape(2, P, 16, NB, 4, 8)   # [half][p][r][b][g][8]
+        q[:] = qt.transpose(4, 0, 3, 1, 2, 5)
+        at = at.reshape(P, 2, 4, NB, 4)                            # [p][half][g4][b][i]
+        a = np.empty((2, P, 4, 4, NB), np.float32)                 # [half][p][g4][i][b]
+        a[:] = at.transpose(1, 0, 2, 4, 3)
+        return q.reshape(-1), a.reshape(-1)
+    sub = dict(w13_q=[], w13_absmax=[], w2_q=[], w2_absmax=[])
+    for e in used:
+        q, a = untile(q13[e].cpu().numpy(), a13[e].cpu().numpy(), 2 * FF, H)
+        sub["w13_q"].append(q), sub["w13_absmax"].append(a)
+        q, a = untile(q2[e].cpu().numpy(), a2[e].cpu().numpy(), H, FF)
+        sub["w2_q"].append(q), sub["w2_absmax"].append(a)
+    sub = {n: np.stack(v) for n, v in sub.items()}
+    ids_s = np.vectorize(remap.get)(ids_h[sample]).astype(np.int32)
+    want = ref.moe_forward(x[sample].cpu().numpy(), ids_s, w_h[sample], **sub, E_local=len(used), H=H, FF=FF, flags=0)
+    _close(out[sample].cpu().numpy(), want)
