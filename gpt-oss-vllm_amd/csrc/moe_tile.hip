@@ -3,14 +3,14 @@
 // A workgroup owns up to 256 tokens of one expert (a token tile) times 256 weight rows (8 row-tile pairs of the tile
 // order that m355_repack_nf4 writes, one pair = 32 rows per wave) and walks K in 64-column blocks, the NF4 absmax
 // block.  Per block:
-//   * each wave fetches its own packed KiB (one global_load_dwordx4 per lane, prefetched one block ahead), turns it
+//   * each wave takes its own packed KiB (brought into LDS by DMA two blocks ahead), turns it
 //     into the A fragments of four v_mfma_f32_32x32x16_f16 (rows = 16 rows of the pair's first tile + the 16 partner
 //     rows) and reuses them for every token of the tile: the weights never pass through LDS and are dequantised once
 //     per 256 tokens.  w = fp16(code * absmax) with the product in fp32, which is bit for bit the weight the
 //     reference's dequantiser produces (patches/streaming_unsloth_bnb.py:192-222);
-//   * the activations of the token tile (256 x 64 fp16 = 32 KiB) are shared by the 8 waves: loaded in whole 128-byte
-//     lines one block ahead into registers, written to one of two LDS buffers after the barrier that frees it, with
-//     the 16-byte chunks XOR-swizzled so that the ds_read_b128 of the B fragments is bank-conflict free.
+//   * the activations of the token tile (256 x 64 fp16 = 32 KiB) are shared by the 8 waves: LDS-DMA
+//     (global_load_lds_dwordx4) in whole 128-byte lines, one block ahead, into one of two buffers, the 16-byte chunks
+//     XOR-swizzled on the source side so that the ds_read_b128 of the B fragments is bank-conflict free.
 // Lane l of a wave = (r = l & 15, s = (l >> 4) & 1, h = l >> 5).  As loaded, lane (r, g = s + 2h) holds 16 codes of
 // row r and 16 of its partner row, columns 16g..16g+15.  One v_permlane16_swap per dword pair trades the partner-row
 // half of the s = 0 lanes against the first-row half of the s = 1 lanes, after which lane (r, s, h) holds row
@@ -28,13 +28,21 @@ constexpr int TG_WAVES = 8;
 constexpr int TG_THREADS = TG_WAVES * 64;
 constexpr int TG_LUT_BYTES = 256 * 256;          // float2 per byte value, 32 replicas of 8 B in a 256-byte row
 constexpr int TG_XBUF = TILE_ROWS * 128;         // one activation buffer: 256 tokens x 64 columns fp16
-constexpr int TG_LDS = TG_LUT_BYTES + 2 * TG_XBUF + 1024;   // + one expert's absmax table
+constexpr int TG_WBUF = TG_WAVES * 1024;         // one packed-weight slot: a KiB per wave
+constexpr int TG_SBUF = TG_WAVES * 256;          // one absmax slot: a dword per lane
+constexpr int TG_X_OFF = TG_LUT_BYTES;
+constexpr int TG_W_OFF = TG_X_OFF + 2 * TG_XBUF;
+constexpr int TG_S_OFF = TG_W_OFF + 2 * TG_WBUF;
+constexpr int TG_TAB_OFF = TG_S_OFF + 2 * TG_SBUF;   // one expert's absmax table (byte absmax)
+constexpr int TG_LDS = TG_TAB_OFF + 1024;
 constexpr int TG_TOKEN_TILES = TILE_ROWS / 32;   // 32-token MFMA tiles per token tile
 
 static __device__ const float nf4_codes[16] = M355_NF4_TABLE;
 
 typedef const float2_t __attribute__((address_space(3))) lds_f2_t;
 typedef const half8_t __attribute__((address_space(3))) lds_h8_t;
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
 
 // 8 weights of one packed dword: four table lookups (address = one v_perm_b32: byte k of d above the lane's replica
 // offset), scaled in fp32, rounded to fp16 (round to nearest even).
@@ -88,31 +96,56 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
     const int pc = live ? p : NP - 1;                       // idle waves run on a valid tile, results dropped
     const int r = lane & 15, s = (lane >> 4) & 1, hh = lane >> 5, n32 = lane & 31;
 
-    // ---- activations: per wave and block 4 loads of 8 tokens x 128 bytes (whole lines), held in registers for one
-    // iteration, then written to the LDS buffer of the next block with the 16-byte chunks XOR-swizzled ----
-    const u32x4_t* xsrc[4];
-    uint32_t xdst[4];
+    // ---- everything that comes from global memory goes to LDS by DMA (global_load_lds), so no vector register waits
+    // for memory and the only waits are the vmcnt(0) + barrier at the top of an iteration ----
+    // activations: per wave and block 4 instructions of 8 tokens x 128 bytes (whole lines); the 16-byte chunk that lane
+    // (token, c') deposits at chunk position c' of the token's LDS line is source chunk c' ^ ((token >> 1) & 7)
+    const half_t* xsrc[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int m = 8 * (4 * wave + j) + (lane >> 3);
         const int pos = pos0 + min(m, mt - 1);
         const int64_t src_row = (MODE == 0) ? (int64_t)(sorted[pos] / k_top) : (int64_t)pos;
-        xsrc[j] = reinterpret_cast<const u32x4_t*>(xin + src_row * K) + (lane & 7);
-        xdst[j] = TG_LUT_BYTES + m * 128 + (((lane & 7) ^ ((m >> 1) & 7)) << 4);
+        xsrc[j] = xin + src_row * K + (((lane & 7) ^ ((m >> 1) & 7)) << 3);
     }
     // B fragment of MFMA step t, token n32 of a 32-token tile: chunk 4h + t of the token's line
     uint32_t boff[4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) boff[t] = TG_LUT_BYTES + n32 * 128 + (((4 * hh + t) ^ ((n32 >> 1) & 7)) << 4);
+    for (int t = 0; t < 4; t++) boff[t] = TG_X_OFF + n32 * 128 + (((4 * hh + t) ^ ((n32 >> 1) & 7)) << 4);
 
-    // ---- weights ----
+    // weights: the wave's packed KiB of a block; absmax: the dword that holds the lane's row (4 code bytes of rows
+    // 4 (r >> 2).. for byte absmax, the row's fp32 otherwise)
     const size_t wq_expert = (size_t)R * K / 2, am_expert = (size_t)R * NB;
-    const u32x4_t* wptr = reinterpret_cast<const u32x4_t*>(wq + (size_t)e * wq_expert + (size_t)pc * NB * 1024) + lane;
-    const size_t am_idx = (((size_t)(pc * 2 + s) * 4 + (r >> 2)) * NB) * 4 + (r & 3);   // + 4 per block
+    const uint8_t* wsrc = wq + (size_t)e * wq_expert + (size_t)pc * NB * 1024 + lane * 16;
     const bool q8 = wam8 != nullptr;
-    const float* amf = q8 ? nullptr : wam + (size_t)e * am_expert + am_idx;
-    const uint8_t* am8 = q8 ? wam8 + (size_t)e * am_expert + am_idx : nullptr;
-    float* ltab = reinterpret_cast<float*>(smem + TG_LUT_BYTES + 2 * TG_XBUF);   // this expert's absmax table (byte absmax)
+    const size_t am_row = ((size_t)(pc * 2 + s) * 4 + (r >> 2)) * NB * 4;
+    const uint8_t* ssrc = q8 ? wam8 + (size_t)e * am_expert + am_row
+                             : reinterpret_cast<const uint8_t*>(wam + (size_t)e * am_expert + am_row + (r & 3));
+    const int sstride = q8 ? 4 : 16;   // bytes per block
+    float* ltab = reinterpret_cast<float*>(smem + TG_TAB_OFF);   // this expert's absmax table (byte absmax)
+    const uint32_t wlds = TG_W_OFF + wave * 1024 + lane * 16, slds = TG_S_OFF + wave * 256 + lane * 4 + (q8 ? (r & 3) : 0);
+
+    auto stage = [&](auto full_tag, int bx, int bw) {   // activations of block bx, weights and absmax of block bw
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int bxc = min(bx, NB - 1), bwc = min(bw, NB - 1);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (FULL || 8 * (4 * wave + j) < mt)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(xsrc[j] + 64 * bxc),
+                                                 (lds_void_t*)(smem + TG_X_OFF + (bx & 1) * TG_XBUF + (4 * wave + j) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc + (size_t)bwc * 1024),
+                                         (lds_void_t*)(smem + TG_W_OFF + (bw & 1) * TG_WBUF + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(ssrc + (size_t)bwc * sstride),
+                                         (lds_void_t*)(smem + TG_S_OFF + (bw & 1) * TG_SBUF + wave * 256), 4, 0, 0);
+    };
+    auto packed_of = [&](int bw) -> u32x4_t {
+        return *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t*>(wlds + (uint32_t)((bw & 1) * TG_WBUF));
+    };
+    auto scale_of = [&](int bw) -> float {
+        const uint32_t a = slds + (uint32_t)((bw & 1) * TG_SBUF);
+        if (q8) return ltab[*reinterpret_cast<const __attribute__((address_space(3))) uint8_t*>(a)];
+        return *reinterpret_cast<const __attribute__((address_space(3))) float*>(a);
+    };
 
     // code table: entry (byte v, replica) = (code[v & 15], code[v >> 4]) as two fp32
     for (int i = tid; i < 256 * 32; i += TG_THREADS) {
@@ -128,89 +161,86 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[c][i] = 0.f;
 
-    // Pipeline.  At the top of iteration b: af = A fragments of block b; w_now = packed block b + 1 (w_free receives
-    // block b + 2); xr = activations of block b + 1 (written to LDS now, then refilled with block b + 2); buffer b & 1
-    // holds the activations of block b.  Iterations come in pairs so that the two weight registers keep static names.
-    // The B fragments of token tile c + 1 are requested before the MFMAs of tile c are issued (two register sets).
-    u32x4_t wA, wB, xr[4];
-    uint32_t cA = 0, cB = 0;      // absmax code (byte absmax) or the fp32 absmax bits of the same blocks as wA / wB
-    half8_t af[4];
-    auto load_w = [&](int b, u32x4_t& wv, uint32_t& cv) {
-        const int bc = min(b, NB - 1);
-        wv = __builtin_nontemporal_load(wptr + (size_t)bc * 64);
-        cv = q8 ? (uint32_t)am8[4 * bc] : __builtin_bit_cast(uint32_t, amf[4 * bc]);
-    };
-    auto scale_of = [&](uint32_t cv) -> float { return q8 ? ltab[cv] : __builtin_bit_cast(float, cv); };
-    auto dequant_all = [&](const u32x4_t& wv, float sc, half8_t* dst) {
-        const auto sw0 = __builtin_amdgcn_permlane16_swap(wv[0], wv[2], false, false);
-        const auto sw1 = __builtin_amdgcn_permlane16_swap(wv[1], wv[3], false, false);
-        dst[0] = dequant8(lbase, sw0[0], sc);
-        dst[1] = dequant8(lbase, sw1[0], sc);
-        dst[2] = dequant8(lbase, sw0[1], sc);
-        dst[3] = dequant8(lbase, sw1[1], sc);
-    };
-
+    // ablation switches (diagnostic builds only)
+#ifdef TG_EXP_NOREAD
+#define TG_EXP_READ(DST, ADDR) DST = a_use[t];
+#else
+#define TG_EXP_READ(DST, ADDR) DST = *reinterpret_cast<lds_h8_t*>(ADDR);
+#endif
+#ifdef TG_EXP_NOMMA
+#define TG_EXP_MMA(ACC, A, B) asm volatile("" ::"v"(A), "v"(B));
+#else
+#define TG_EXP_MMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, ACC, 0, 0, 0);
+#endif
+#ifdef TG_EXP_NODEQ
+#define TG_EXP_DEQ(X)
+#else
+#define TG_EXP_DEQ(X) X
+#endif
+    // Pipeline.  Iteration b multiplies block b (A fragments a_use, activations in buffer b & 1) and meanwhile turns
+    // packed block b + 1 (LDS slot (b + 1) & 1, brought in during iteration b - 1) into a_fill, one dword after each
+    // of four token tiles, while the DMA brings activations b + 1 and weights b + 2.  The B fragments of token tile
+    // c + 1 are requested before the MFMAs of tile c are issued (two register sets).  Iterations come in pairs so
+    // that the two A-fragment sets keep static names.
+    half8_t afA[4], afB[4];
     auto main_loop = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;   // all 8 token tiles live: no per-tile tests
-        auto load_x = [&](int b) {
-            const int bc = min(b, NB - 1);
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (FULL || 8 * (4 * wave + j) < mt) xr[j] = xsrc[j][8 * bc];
-        };
-        auto write_x = [&](int buf) {
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (FULL || 8 * (4 * wave + j) < mt)
-                    *reinterpret_cast<__attribute__((address_space(3))) u32x4_t*>(xdst[j] + (uint32_t)(buf * TG_XBUF)) = xr[j];
-        };
-        load_x(0);
-        load_w(0, wB, cB);
-        load_w(1, wA, cA);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // both tables are complete
-        write_x(0);
-        load_x(1);
-        dequant_all(wB, scale_of(cB), af);
-
-        auto iteration = [&](int b, u32x4_t& w_now, uint32_t& c_now, u32x4_t& w_free, uint32_t& c_free) {
-            // every wave's part of block b's activations is in buffer b & 1; nobody reads buffer (b + 1) & 1 any more
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            write_x((b + 1) & 1);           // (block b + 1; unused after the last block)
-            load_x(b + 2);
-            load_w(b + 2, w_free, c_free);
+        stage(full_tag, 0, 0);
+        stage(full_tag, 0, 1);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tables complete, block 0 landed
+        {
+            const u32x4_t wv = packed_of(0);
+            const float sc = scale_of(0);
+            const auto sw0 = __builtin_amdgcn_permlane16_swap(wv[0], wv[2], false, false);
+            const auto sw1 = __builtin_amdgcn_permlane16_swap(wv[1], wv[3], false, false);
+            afA[0] = dequant8(lbase, sw0[0], sc);
+            afA[1] = dequant8(lbase, sw1[0], sc);
+            afA[2] = dequant8(lbase, sw0[1], sc);
+            afA[3] = dequant8(lbase, sw1[1], sc);
+        }
+        auto iteration = [&](int b, half8_t* a_use, half8_t* a_fill) {
+            // every DMA of the last iteration has landed (this wave's: vmcnt; the others': barrier), and nobody reads
+            // what this iteration's DMA overwrites
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            stage(full_tag, b + 1, b + 2);
+            const u32x4_t wv = packed_of(b + 1);
+            const float sc = scale_of(b + 1);
+            const auto sw0 = __builtin_amdgcn_permlane16_swap(wv[0], wv[2], false, false);
+            const auto sw1 = __builtin_amdgcn_permlane16_swap(wv[1], wv[3], false, false);
             const uint32_t xb = (uint32_t)((b & 1) * TG_XBUF);
+            lds_h8_t* bp[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) bp[t] = reinterpret_cast<lds_h8_t*>(boff[t] + xb);
             half8_t bfA[4], bfB[4];
 #define TG_READ(BF, C)                                                                                          \
     if (FULL || (C) < ntt) {                                                                                    \
-        _Pragma("unroll") for (int t = 0; t < 4; t++)                                                           \
-            BF[t] = *reinterpret_cast<lds_h8_t*>(boff[t] + xb + (uint32_t)((C) * 4096));                        \
+        _Pragma("unroll") for (int t = 0; t < 4; t++) TG_EXP_READ(BF[t], bp[t] + (C) * 256)                     \
     }
 #define TG_MMA(BF, C)                                                                                           \
     if (FULL || (C) < ntt) {                                                                                    \
-        _Pragma("unroll") for (int t = 0; t < 4; t++)                                                           \
-            acc[C] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], BF[t], acc[C], 0, 0, 0);                     \
+        _Pragma("unroll") for (int t = 0; t < 4; t++) TG_EXP_MMA(acc[C], a_use[t], BF[t])                       \
     }
 #define TG_SB __builtin_amdgcn_sched_barrier(0);   /* keeps the order: reads of tile c + 1, then MFMAs of tile c */
             TG_SB TG_READ(bfA, 0)
             TG_SB TG_READ(bfB, 1) TG_SB TG_MMA(bfA, 0)
-            TG_SB TG_READ(bfA, 2) TG_SB TG_MMA(bfB, 1)
+            TG_SB TG_READ(bfA, 2) TG_SB TG_MMA(bfB, 1) TG_EXP_DEQ(a_fill[0] = dequant8(lbase, sw0[0], sc);)
             TG_SB TG_READ(bfB, 3) TG_SB TG_MMA(bfA, 2)
-            TG_SB TG_READ(bfA, 4) TG_SB TG_MMA(bfB, 3)
+            TG_SB TG_READ(bfA, 4) TG_SB TG_MMA(bfB, 3) TG_EXP_DEQ(a_fill[1] = dequant8(lbase, sw1[0], sc);)
             TG_SB TG_READ(bfB, 5) TG_SB TG_MMA(bfA, 4)
-            TG_SB TG_READ(bfA, 6) TG_SB TG_MMA(bfB, 5)
+            TG_SB TG_READ(bfA, 6) TG_SB TG_MMA(bfB, 5) TG_EXP_DEQ(a_fill[2] = dequant8(lbase, sw0[1], sc);)
             TG_SB TG_READ(bfB, 7) TG_SB TG_MMA(bfA, 6)
-            TG_SB TG_MMA(bfB, 7) TG_SB
+            TG_SB TG_MMA(bfB, 7) TG_EXP_DEQ(a_fill[3] = dequant8(lbase, sw1[1], sc);) TG_SB
 #undef TG_SB
 #undef TG_READ
 #undef TG_MMA
-            dequant_all(w_now, scale_of(c_now), af);   // block b + 1
         };
         int b = 0;
         for (; b + 1 < NB; b += 2) {
-            iteration(b, wA, cA, wB, cB);
-            iteration(b + 1, wB, cB, wA, cA);
+            iteration(b, afA, afB);
+            iteration(b + 1, afB, afA);
         }
-        if (b < NB) iteration(b, wA, cA, wB, cB);
+        if (b < NB) iteration(b, afA, afB);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last iterations' DMA re-reads the last block)
     };
     if (ntt == TG_TOKEN_TILES) main_loop(std::true_type{});
     else main_loop(std::false_type{});
