@@ -800,7 +800,7 @@ static int tile_gemm_device_setup_once(int dev) {
 }
 
 // mean (token, k) pairs per local expert from which the tile kernel takes over
-constexpr int TILE_MIN_MEAN_PAIRS = 24;
+constexpr int TILE_MIN_MEAN_PAIRS = 40;   // measured crossover on gpt-oss-20b shapes (32 experts: about 320 tokens)
 
 static int stream_lds_bytes(int pairs, bool inline_route) {   // (activations live in registers)
     return LUTP_BYTES + 2 * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4 + (inline_route ? (int)align_up(sizeof(InlineTables), 16) : 0);

@@ -24,12 +24,14 @@ namespace m355 {
 typedef float float16_t __attribute__((ext_vector_type(16)));
 typedef float float2_t __attribute__((ext_vector_type(2)));
 
-constexpr int TG_WAVES = 8;
+constexpr int TG_WAVES = 8;                      // two waves per SIMD (one wave per SIMD with TG_RT = 2 measured 10 % slower)
+constexpr int TG_RT = 1;                         // row-tile pairs (32 weight rows each) per wave
 constexpr int TG_THREADS = TG_WAVES * 64;
 constexpr int TG_LUT_BYTES = 256 * 256;          // float2 per byte value, 32 replicas of 8 B in a 256-byte row
 constexpr int TG_XBUF = TILE_ROWS * 128;         // one activation buffer: 256 tokens x 64 columns fp16
-constexpr int TG_WBUF = TG_WAVES * 1024;         // one packed-weight slot: a KiB per wave
-constexpr int TG_SBUF = TG_WAVES * 256;          // one absmax slot: a dword per lane
+constexpr int TG_XI = TILE_ROWS / 8 / TG_WAVES;  // activation DMA instructions (8 tokens each) per wave and block
+constexpr int TG_WBUF = TG_WAVES * TG_RT * 1024; // one packed-weight slot: a KiB per pair
+constexpr int TG_SBUF = TG_WAVES * TG_RT * 256;  // one absmax slot: a dword per lane and pair
 constexpr int TG_X_OFF = TG_LUT_BYTES;
 constexpr int TG_W_OFF = TG_X_OFF + 2 * TG_XBUF;
 constexpr int TG_S_OFF = TG_W_OFF + 2 * TG_WBUF;
@@ -91,19 +93,17 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
     const int pos0 = offsets[e] + tile_m0[tt];
     const int mt = min(TILE_ROWS, offsets[e + 1] - pos0);
     const int ntt = (mt + 31) >> 5;                         // live 32-token tiles
-    const int p = rg * TG_WAVES + wave;
-    const bool live = p < NP;
-    const int pc = live ? p : NP - 1;                       // idle waves run on a valid tile, results dropped
+    const int p0 = (rg * TG_WAVES + wave) * TG_RT;          // this wave's row-tile pairs: p0 .. p0 + TG_RT - 1
     const int r = lane & 15, s = (lane >> 4) & 1, hh = lane >> 5, n32 = lane & 31;
 
     // ---- everything that comes from global memory goes to LDS by DMA (global_load_lds), so no vector register waits
     // for memory and the only waits are the vmcnt(0) + barrier at the top of an iteration ----
-    // activations: per wave and block 4 instructions of 8 tokens x 128 bytes (whole lines); the 16-byte chunk that lane
-    // (token, c') deposits at chunk position c' of the token's LDS line is source chunk c' ^ ((token >> 1) & 7)
-    const half_t* xsrc[4];
+    // activations: per wave and block TG_XI instructions of 8 tokens x 128 bytes (whole lines); the 16-byte chunk that
+    // lane (token, c') deposits at chunk position c' of the token's LDS line is source chunk c' ^ ((token >> 1) & 7)
+    const half_t* xsrc[TG_XI];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int m = 8 * (4 * wave + j) + (lane >> 3);
+    for (int j = 0; j < TG_XI; j++) {
+        const int m = 8 * (TG_XI * wave + j) + (lane >> 3);
         const int pos = pos0 + min(m, mt - 1);
         const int64_t src_row = (MODE == 0) ? (int64_t)(sorted[pos] / k_top) : (int64_t)pos;
         xsrc[j] = xin + src_row * K + (((lane & 7) ^ ((m >> 1) & 7)) << 3);
@@ -113,36 +113,46 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
 #pragma unroll
     for (int t = 0; t < 4; t++) boff[t] = TG_X_OFF + n32 * 128 + (((4 * hh + t) ^ ((n32 >> 1) & 7)) << 4);
 
-    // weights: the wave's packed KiB of a block; absmax: the dword that holds the lane's row (4 code bytes of rows
-    // 4 (r >> 2).. for byte absmax, the row's fp32 otherwise)
+    // weights: a packed KiB per pair and block; absmax: the dword that holds the lane's row (4 code bytes of rows
+    // 4 (r >> 2).. for byte absmax, the row's fp32 otherwise).  Pairs past the end re-read the last one, results dropped.
     const size_t wq_expert = (size_t)R * K / 2, am_expert = (size_t)R * NB;
-    const uint8_t* wsrc = wq + (size_t)e * wq_expert + (size_t)pc * NB * 1024 + lane * 16;
     const bool q8 = wam8 != nullptr;
-    const size_t am_row = ((size_t)(pc * 2 + s) * 4 + (r >> 2)) * NB * 4;
-    const uint8_t* ssrc = q8 ? wam8 + (size_t)e * am_expert + am_row
-                             : reinterpret_cast<const uint8_t*>(wam + (size_t)e * am_expert + am_row + (r & 3));
     const int sstride = q8 ? 4 : 16;   // bytes per block
+    const uint8_t* wsrc[TG_RT];
+    const uint8_t* ssrc[TG_RT];
+#pragma unroll
+    for (int i = 0; i < TG_RT; i++) {
+        const int pc = min(p0 + i, NP - 1);
+        wsrc[i] = wq + (size_t)e * wq_expert + (size_t)pc * NB * 1024 + lane * 16;
+        const size_t am_row = ((size_t)(pc * 2 + s) * 4 + (r >> 2)) * NB * 4;
+        ssrc[i] = q8 ? wam8 + (size_t)e * am_expert + am_row
+                     : reinterpret_cast<const uint8_t*>(wam + (size_t)e * am_expert + am_row + (r & 3));
+    }
     float* ltab = reinterpret_cast<float*>(smem + TG_TAB_OFF);   // this expert's absmax table (byte absmax)
-    const uint32_t wlds = TG_W_OFF + wave * 1024 + lane * 16, slds = TG_S_OFF + wave * 256 + lane * 4 + (q8 ? (r & 3) : 0);
+    const uint32_t wlds = TG_W_OFF + wave * TG_RT * 1024 + lane * 16;
+    const uint32_t slds = TG_S_OFF + wave * TG_RT * 256 + lane * 4 + (q8 ? (r & 3) : 0);
 
     auto stage = [&](auto full_tag, int bx, int bw) {   // activations of block bx, weights and absmax of block bw
         constexpr bool FULL = decltype(full_tag)::value;
         const int bxc = min(bx, NB - 1), bwc = min(bw, NB - 1);
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-            if (FULL || 8 * (4 * wave + j) < mt)
+        for (int j = 0; j < TG_XI; j++)
+            if (FULL || 8 * (TG_XI * wave + j) < mt)
                 __builtin_amdgcn_global_load_lds((glb_void_t*)(xsrc[j] + 64 * bxc),
-                                                 (lds_void_t*)(smem + TG_X_OFF + (bx & 1) * TG_XBUF + (4 * wave + j) * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc + (size_t)bwc * 1024),
-                                         (lds_void_t*)(smem + TG_W_OFF + (bw & 1) * TG_WBUF + wave * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void_t*)(ssrc + (size_t)bwc * sstride),
-                                         (lds_void_t*)(smem + TG_S_OFF + (bw & 1) * TG_SBUF + wave * 256), 4, 0, 0);
+                                                 (lds_void_t*)(smem + TG_X_OFF + (bx & 1) * TG_XBUF + (TG_XI * wave + j) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TG_RT; i++) {
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc[i] + (size_t)bwc * 1024),
+                                             (lds_void_t*)(smem + TG_W_OFF + (bw & 1) * TG_WBUF + (wave * TG_RT + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(ssrc[i] + (size_t)bwc * sstride),
+                                             (lds_void_t*)(smem + TG_S_OFF + (bw & 1) * TG_SBUF + (wave * TG_RT + i) * 256), 4, 0, 0);
+        }
     };
-    auto packed_of = [&](int bw) -> u32x4_t {
-        return *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t*>(wlds + (uint32_t)((bw & 1) * TG_WBUF));
+    auto packed_of = [&](int bw, int i) -> u32x4_t {
+        return *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t*>(wlds + (uint32_t)((bw & 1) * TG_WBUF + i * 1024));
     };
-    auto scale_of = [&](int bw) -> float {
-        const uint32_t a = slds + (uint32_t)((bw & 1) * TG_SBUF);
+    auto scale_of = [&](int bw, int i) -> float {
+        const uint32_t a = slds + (uint32_t)((bw & 1) * TG_SBUF + i * 256);
         if (q8) return ltab[*reinterpret_cast<const __attribute__((address_space(3))) uint8_t*>(a)];
         return *reinterpret_cast<const __attribute__((address_space(3))) float*>(a);
     };
@@ -155,15 +165,17 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
     if (q8 && tid < 256) ltab[tid] = wtab[(size_t)e * 256 + tid];
     const uint32_t lbase = (uint32_t)(n32 * 8);   // the table starts at LDS address 0 (no static LDS in this kernel)
 
-    float16_t acc[TG_TOKEN_TILES];
+    float16_t acc[TG_RT][TG_TOKEN_TILES];
 #pragma unroll
-    for (int c = 0; c < TG_TOKEN_TILES; c++)
+    for (int i = 0; i < TG_RT; i++)
 #pragma unroll
-        for (int i = 0; i < 16; i++) acc[c][i] = 0.f;
+        for (int c = 0; c < TG_TOKEN_TILES; c++)
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc[i][c][q] = 0.f;
 
     // ablation switches (diagnostic builds only)
 #ifdef TG_EXP_NOREAD
-#define TG_EXP_READ(DST, ADDR) DST = a_use[t];
+#define TG_EXP_READ(DST, ADDR) DST = a_use[0][t];
 #else
 #define TG_EXP_READ(DST, ADDR) DST = *reinterpret_cast<lds_h8_t*>(ADDR);
 #endif
@@ -178,35 +190,42 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
 #define TG_EXP_DEQ(X) X
 #endif
     // Pipeline.  Iteration b multiplies block b (A fragments a_use, activations in buffer b & 1) and meanwhile turns
-    // packed block b + 1 (LDS slot (b + 1) & 1, brought in during iteration b - 1) into a_fill, one dword after each
-    // of four token tiles, while the DMA brings activations b + 1 and weights b + 2.  The B fragments of token tile
-    // c + 1 are requested before the MFMAs of tile c are issued (two register sets).  Iterations come in pairs so
-    // that the two A-fragment sets keep static names.
-    half8_t afA[4], afB[4];
+    // packed block b + 1 (LDS slot (b + 1) & 1, brought in during iteration b - 1) into a_fill, a dword at a time
+    // between the MFMAs of the token tiles, while the DMA brings activations b + 1 and weights b + 2.  The B fragments
+    // of token tile c + 1 are requested before the MFMAs of tile c are issued (two register sets).  Iterations come
+    // in pairs so that the two A-fragment sets keep static names.
+    half8_t afA[TG_RT][4], afB[TG_RT][4];
     auto main_loop = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;   // all 8 token tiles live: no per-tile tests
         stage(full_tag, 0, 0);
         stage(full_tag, 0, 1);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tables complete, block 0 landed
-        {
-            const u32x4_t wv = packed_of(0);
-            const float sc = scale_of(0);
+#pragma unroll
+        for (int i = 0; i < TG_RT; i++) {
+            const u32x4_t wv = packed_of(0, i);
+            const float sc = scale_of(0, i);
             const auto sw0 = __builtin_amdgcn_permlane16_swap(wv[0], wv[2], false, false);
             const auto sw1 = __builtin_amdgcn_permlane16_swap(wv[1], wv[3], false, false);
-            afA[0] = dequant8(lbase, sw0[0], sc);
-            afA[1] = dequant8(lbase, sw1[0], sc);
-            afA[2] = dequant8(lbase, sw0[1], sc);
-            afA[3] = dequant8(lbase, sw1[1], sc);
+            afA[i][0] = dequant8(lbase, sw0[0], sc);
+            afA[i][1] = dequant8(lbase, sw1[0], sc);
+            afA[i][2] = dequant8(lbase, sw0[1], sc);
+            afA[i][3] = dequant8(lbase, sw1[1], sc);
         }
-        auto iteration = [&](int b, half8_t* a_use, half8_t* a_fill) {
+        auto iteration = [&](int b, half8_t (*a_use)[4], half8_t (*a_fill)[4]) {
             // every DMA of the last iteration has landed (this wave's: vmcnt; the others': barrier), and nobody reads
             // what this iteration's DMA overwrites
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             stage(full_tag, b + 1, b + 2);
-            const u32x4_t wv = packed_of(b + 1);
-            const float sc = scale_of(b + 1);
-            const auto sw0 = __builtin_amdgcn_permlane16_swap(wv[0], wv[2], false, false);
-            const auto sw1 = __builtin_amdgcn_permlane16_swap(wv[1], wv[3], false, false);
+            uint32_t dw[TG_RT][4];   // packed block b + 1 in MFMA-step order
+            float sc[TG_RT];
+#pragma unroll
+            for (int i = 0; i < TG_RT; i++) {
+                const u32x4_t wv = packed_of(b + 1, i);
+                sc[i] = scale_of(b + 1, i);
+                const auto sw0 = __builtin_amdgcn_permlane16_swap(wv[0], wv[2], false, false);
+                const auto sw1 = __builtin_amdgcn_permlane16_swap(wv[1], wv[3], false, false);
+                dw[i][0] = sw0[0]; dw[i][1] = sw1[0]; dw[i][2] = sw0[1]; dw[i][3] = sw1[1];
+            }
             const uint32_t xb = (uint32_t)((b & 1) * TG_XBUF);
             lds_h8_t* bp[4];
 #pragma unroll
@@ -218,19 +237,26 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
     }
 #define TG_MMA(BF, C)                                                                                           \
     if (FULL || (C) < ntt) {                                                                                    \
-        _Pragma("unroll") for (int t = 0; t < 4; t++) TG_EXP_MMA(acc[C], a_use[t], BF[t])                       \
+        _Pragma("unroll") for (int t = 0; t < 4; t++)                                                           \
+            _Pragma("unroll") for (int i = 0; i < TG_RT; i++) TG_EXP_MMA(acc[i][C], a_use[i][t], BF[t])         \
     }
+            /* one dword (8 weights) of the next block per token tile and pair: parts 0..3 of pair 0 behind tiles */ \
+            /* 0, 2, 4, 6; of pair 1 behind tiles 1, 3, 5, 7 */
+#define TG_DEQ(C)                                                                                               \
+    TG_EXP_DEQ(if (((C) & 1) < TG_RT) a_fill[(C) & 1][(C) >> 1] = dequant8(lbase, dw[(C) & 1][(C) >> 1], sc[(C) & 1]);) \
+    TG_EXP_DEQ(if (TG_RT == 1 && ((C) & 1)) {})
 #define TG_SB __builtin_amdgcn_sched_barrier(0);   /* keeps the order: reads of tile c + 1, then MFMAs of tile c */
             TG_SB TG_READ(bfA, 0)
-            TG_SB TG_READ(bfB, 1) TG_SB TG_MMA(bfA, 0)
-            TG_SB TG_READ(bfA, 2) TG_SB TG_MMA(bfB, 1) TG_EXP_DEQ(a_fill[0] = dequant8(lbase, sw0[0], sc);)
-            TG_SB TG_READ(bfB, 3) TG_SB TG_MMA(bfA, 2)
-            TG_SB TG_READ(bfA, 4) TG_SB TG_MMA(bfB, 3) TG_EXP_DEQ(a_fill[1] = dequant8(lbase, sw1[0], sc);)
-            TG_SB TG_READ(bfB, 5) TG_SB TG_MMA(bfA, 4)
-            TG_SB TG_READ(bfA, 6) TG_SB TG_MMA(bfB, 5) TG_EXP_DEQ(a_fill[2] = dequant8(lbase, sw0[1], sc);)
-            TG_SB TG_READ(bfB, 7) TG_SB TG_MMA(bfA, 6)
-            TG_SB TG_MMA(bfB, 7) TG_EXP_DEQ(a_fill[3] = dequant8(lbase, sw1[1], sc);) TG_SB
+            TG_SB TG_READ(bfB, 1) TG_SB TG_MMA(bfA, 0) TG_DEQ(0)
+            TG_SB TG_READ(bfA, 2) TG_SB TG_MMA(bfB, 1) TG_DEQ(1)
+            TG_SB TG_READ(bfB, 3) TG_SB TG_MMA(bfA, 2) TG_DEQ(2)
+            TG_SB TG_READ(bfA, 4) TG_SB TG_MMA(bfB, 3) TG_DEQ(3)
+            TG_SB TG_READ(bfB, 5) TG_SB TG_MMA(bfA, 4) TG_DEQ(4)
+            TG_SB TG_READ(bfA, 6) TG_SB TG_MMA(bfB, 5) TG_DEQ(5)
+            TG_SB TG_READ(bfB, 7) TG_SB TG_MMA(bfA, 6) TG_DEQ(6)
+            TG_SB TG_MMA(bfB, 7) TG_DEQ(7) TG_SB
 #undef TG_SB
+#undef TG_DEQ
 #undef TG_READ
 #undef TG_MMA
         };
@@ -245,39 +271,43 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
     if (ntt == TG_TOKEN_TILES) main_loop(std::true_type{});
     else main_loop(std::false_type{});
 
-    // ---- epilogue: accumulator register i of lane (n32, h) is token n32, row (i & 3) + 8 (i >> 2) + 4h of the
+    // ---- epilogue: accumulator register q of lane (n32, h) is token n32, row (q & 3) + 8 (q >> 2) + 4h of the
     // 32-row tile; rows 0..15 are the pair's first tile (16p + ..), rows 16..31 its partner (16 (p + NP) + ..)
-    if (!live) return;
-    float ba[8], bb[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-        ba[i] = sp.bias ? (float)sp.bias[(int64_t)e * R + 16 * p + row] : 0.f;
-        bb[i] = sp.bias ? (float)sp.bias[(int64_t)e * R + 16 * (p + NP) + row] : 0.f;
-    }
+    for (int i = 0; i < TG_RT; i++) {
+        const int p = p0 + i;
+        if (p >= NP) continue;
+        float ba[8], bb[8];
 #pragma unroll
-    for (int c = 0; c < TG_TOKEN_TILES; c++) {
-        const int m = 32 * c + n32;
-        if (m < mt) {
-            const int64_t orow = pos0 + m;
+        for (int q = 0; q < 8; q++) {
+            const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+            ba[q] = sp.bias ? (float)sp.bias[(int64_t)e * R + 16 * p + row] : 0.f;
+            bb[q] = sp.bias ? (float)sp.bias[(int64_t)e * R + 16 * (p + NP) + row] : 0.f;
+        }
 #pragma unroll
-            for (int q = 0; q < 2; q++) {   // rows 4h.. and 8 + 4h..
-                half4_t va, vb;
+        for (int c = 0; c < TG_TOKEN_TILES; c++) {
+            const int m = 32 * c + n32;
+            if (m < mt) {
+                const int64_t orow = pos0 + m;
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const float a = acc[c][4 * q + i] + ba[4 * q + i], bq = acc[c][8 + 4 * q + i] + bb[4 * q + i];
-                    if (MODE == 0) {
-                        va[i] = (half_t)act_pair(a, bq, sp);
-                    } else {
-                        va[i] = (half_t)a;
-                        vb[i] = (half_t)bq;
+                for (int g = 0; g < 2; g++) {   // rows 4h.. and 8 + 4h..
+                    half4_t va, vb;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float a = acc[i][c][4 * g + q] + ba[4 * g + q], bq = acc[i][c][8 + 4 * g + q] + bb[4 * g + q];
+                        if (MODE == 0) {
+                            va[q] = (half_t)act_pair(a, bq, sp);
+                        } else {
+                            va[q] = (half_t)a;
+                            vb[q] = (half_t)bq;
+                        }
                     }
-                }
-                if (MODE == 0) {
-                    *reinterpret_cast<half4_t*>(outp + orow * (R / 2) + 16 * p + 8 * q + 4 * hh) = va;
-                } else {
-                    *reinterpret_cast<half4_t*>(outp + orow * R + 16 * p + 8 * q + 4 * hh) = va;
-                    *reinterpret_cast<half4_t*>(outp + orow * R + 16 * (p + NP) + 8 * q + 4 * hh) = vb;
+                    if (MODE == 0) {
+                        *reinterpret_cast<half4_t*>(outp + orow * (R / 2) + 16 * p + 8 * g + 4 * hh) = va;
+                    } else {
+                        *reinterpret_cast<half4_t*>(outp + orow * R + 16 * p + 8 * g + 4 * hh) = va;
+                        *reinterpret_cast<half4_t*>(outp + orow * R + 16 * (p + NP) + 8 * g + 4 * hh) = vb;
+                    }
                 }
             }
         }
@@ -296,7 +326,7 @@ int launch_tile_gemm(int mode, const half_t* xin, const uint8_t* wq, const float
                      const float* wtab, const MoeWorkspace& ws, int K, int R, int k_top, int max_tiles, half_t* outp,
                      const StageParams& sp, hipStream_t st) {
     const int NP = R / 32;
-    const int n_rg = (NP + TG_WAVES - 1) / TG_WAVES;
+    const int n_rg = (NP + TG_WAVES * TG_RT - 1) / (TG_WAVES * TG_RT);
     const int64_t blocks = (int64_t)8 * ((max_tiles + 7) / 8) * n_rg;
     if (blocks <= 0 || blocks > 0x7fffffff) return fail(-2, "m355_moe_nf4_forward: %lld workgroups", (long long)blocks);
     if (mode == 0)
