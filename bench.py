@@ -293,6 +293,68 @@ def full_layer_leg(lib, main_step, batch, ctx, layers, device, steps, warmup):
             "dense_projection_bytes_per_step": dense_bytes}
 
 
+def prefill_leg(lib, main_step, device, tokens, reps=3):
+    """The same experts fed a prefill-sized batch (BASELINE configs[4] is an 8k-token prefill): per layer router top-k
+    + fused NF4 MoE, where the library picks its kernel for many tokens per expert (256-token tiles, weights
+    dequantised once per tile, MFMA-bound).  Attention prefill is not part of the path built here.  The MFMA figure
+    times the gate_up launches alone (one HIP graph of all layers, HIP events on the launch stream)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(8192)
+    T = tokens
+    x = torch.randn((T, H), device=device, generator=g).half()
+    ids = torch.empty((T, TOPK), dtype=torch.int32, device=device)
+    w = torch.empty((T, TOPK), dtype=torch.float32, device=device)
+    out = torch.empty((T, H), dtype=torch.float16, device=device)
+    ws = torch.empty(lib.moe_workspace_bytes(T, TOPK, H, FF, E), dtype=torch.uint8, device=device)
+    F = lib.FLAG_FP16_COMBINE
+
+    def run(flags, route=True):
+        for lay in main_step.L:
+            if route:
+                lib.router_topk(x, lay["wr"], None, TOPK, ids=ids, w=w)
+            lib.moe_nf4_forward(x, ids, w, lay["w13_q"], lay["w13_a"], lay["w2_q"], lay["w2_a"], E_local=E, e_first=0,
+                                H=H, FF=FF, workspace=ws, out=out, flags=flags)
+
+    def graph_time(fn):
+        fn()
+        torch.cuda.synchronize()
+        s_ = torch.cuda.Stream()
+        s_.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s_):
+            fn()
+        torch.cuda.current_stream().wait_stream(s_)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            fn()
+        gr.replay()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            gr.replay()
+        b.record()
+        b.synchronize()
+        return a.elapsed_time(b) * 1e-3 / reps
+
+    t_all = graph_time(lambda: run(F))
+    only_gate_up = F | lib.FLAG_SKIP_ROUTE | lib.FLAG_SKIP_DOWN | lib.FLAG_SKIP_COMBINE
+    only_down = F | lib.FLAG_SKIP_ROUTE | lib.FLAG_SKIP_GATE_UP | lib.FLAG_SKIP_COMBINE
+    t_gu = graph_time(lambda: run(only_gate_up, route=False)) / len(main_step.L)
+    t_dn = graph_time(lambda: run(only_down, route=False)) / len(main_step.L)
+    fl_gu = float(T) * TOPK * GATE_UP_FLOPS_PER_PAIR
+    return {
+        "value": T / t_all, "unit": "tokens/s", "tokens": T, "ms_per_layer": t_all / len(main_step.L) * 1e3,
+        "what": f"{T}-token prefill through router top-k + fused NF4 MoE of {len(main_step.L)} layers (32 experts, top-4: "
+                f"about {T * TOPK // E} tokens per expert), one HIP graph; attention prefill not included",
+        "roofline": {"bound": "mfma", "kernel": "moe_tile_gemm_kernel<gate_up> (NF4 dequant fused into the grouped GEMM, 256-token tiles)",
+                     "achieved": fl_gu / t_gu / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": fl_gu / t_gu / 1e12 / MFMA_PEAK_TFLOPS, "avg_us": t_gu * 1e6, "flops_per_launch": fl_gu,
+                     "down_kernel": {"achieved": fl_gu / 2 / t_dn / 1e12, "avg_us": t_dn * 1e6,
+                                     "frac": fl_gu / 2 / t_dn / 1e12 / MFMA_PEAK_TFLOPS}},
+    }
+
+
 def load_leg(device):
     """Checkpoint -> GPU-resident tile-order weights for one full-size layer (32 experts): a synthetic shard in the
     Unsloth key schema is written to a temporary directory, then read through the plug-in's weight_loader and
@@ -345,6 +407,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="one-rank rehearsal of the multi-GPU path: initialise RCCL and run the token exchange even at --gpus 1")
     ap.add_argument("--graph-dist", action="store_true", help="capture the step in a HIP graph even when it holds collectives")
+    ap.add_argument("--prefill-tokens", type=int, default=8192,
+                    help="also run a prefill-sized batch through the MoE path (0 = skip): the MFMA-bound leg")
     ap.add_argument("--load-leg", action="store_true", help="also time checkpoint -> GPU weights for one layer")
     ap.add_argument("--full-layer-leg", action="store_true", help="also time the whole decoder stack (bs = --batch-per-gpu and 1)")
     a = ap.parse_args()
@@ -430,6 +494,8 @@ def main():
             # the same launch priced against the matrix cores: decode at 4 tokens per expert is far left of the ridge
             "mfma": {"achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS},
         }
+    if rank == 0 and world == 1 and a.prefill_tokens > 0:
+        result["prefill"] = prefill_leg(lib, main_step, device, a.prefill_tokens)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
     if rank == 0 and world == 1 and a.full_layer_leg:
