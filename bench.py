@@ -345,7 +345,7 @@ def prefill_leg(lib, main_step, device, tokens, reps=3):
     fl_gu = float(T) * TOPK * GATE_UP_FLOPS_PER_PAIR
     return {
         "value": T / t_all, "unit": "tokens/s", "tokens": T, "ms_per_layer": t_all / len(main_step.L) * 1e3,
-        "what": f"{T}-token prefill through router top-k + fused NF4 MoE of {len(main_step.L)} layers (32 experts, top-4: "
+        "what": f"{T}-token prefill through router top-k + fused NF4 MoE of {len(main_step.L)} layers ({E} experts, top-4: "
                 f"about {T * TOPK // E} tokens per expert), one HIP graph; attention prefill not included",
         "roofline": {"bound": "mfma", "kernel": "moe_tile_gemm_kernel<gate_up> (NF4 dequant fused into the grouped GEMM, 256-token tiles)",
                      "achieved": fl_gu / t_gu / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -396,7 +396,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--ctx", type=int, default=256)
-    ap.add_argument("--layers", type=int, default=LAYERS)
+    ap.add_argument("--shape", choices=("20b", "120b"), default="20b",
+                    help="20b: 32 experts, 24 layers (BASELINE configs[1..3]); 120b: 128 experts, 36 layers (the shape of configs[4])")
+    ap.add_argument("--layers", type=int, default=None)
     ap.add_argument("--eager", action="store_true", help="do not capture the step in a HIP graph")
     ap.add_argument("--absmax", choices=("u8", "fp32"), default="u8",
                     help="absmax storage: u8 = the checkpoint's code byte per block + a 256-entry table per expert (default), "
@@ -412,6 +414,11 @@ def main():
     ap.add_argument("--load-leg", action="store_true", help="also time checkpoint -> GPU weights for one layer")
     ap.add_argument("--full-layer-leg", action="store_true", help="also time the whole decoder stack (bs = --batch-per-gpu and 1)")
     a = ap.parse_args()
+    global E, LAYERS
+    if a.shape == "120b":
+        E, LAYERS = 128, 36
+    if a.layers is None:
+        a.layers = LAYERS
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -443,14 +450,14 @@ def main():
     dt = timed(main_step, a.steps, a.warmup, world)
     tokens = a.batch_per_gpu * world
     result = {
-        "metric": "decode tokens/sec gpt-oss-20b NF4 (hot path: paged-attn + router + fused NF4 MoE, 24 layers)",
+        "metric": f"decode tokens/sec gpt-oss-{a.shape} NF4 (hot path: paged-attn + router + fused NF4 MoE, {a.layers} layers)",
         "value": tokens * a.steps / dt, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
         "config": {
-            "workload": (f"gpt-oss-20b-shaped NF4 decode, bs={a.batch_per_gpu} per GPU (global {tokens}), ctx {a.ctx}, "
-                         f"{a.layers} layers, H=FF=2880, E=32 top-4, 64q/8kv heads d=64; "
-                         + ("1 GPU: BASELINE configs[2]" if world == 1 else f"experts sharded over {world} GPUs (EP, all-to-all): BASELINE configs[3] shape")),
+            "workload": (f"gpt-oss-{a.shape}-shaped NF4 decode, bs={a.batch_per_gpu} per GPU (global {tokens}), ctx {a.ctx}, "
+                         f"{a.layers} layers, H=FF=2880, E={E} top-4, 64q/8kv heads d=64; "
+                         + (("1 GPU: BASELINE configs[2]" if a.shape == "20b" else "1 GPU, the model shape of BASELINE configs[4]") if world == 1 else f"experts sharded over {world} GPUs (EP, all-to-all): BASELINE configs[3] shape")),
             "batch_per_gpu": a.batch_per_gpu, "global_batch": tokens, "seq_len": a.ctx,
             "parallelism": "single" if world == 1 else f"ep{world}+dp{world}", "hip_graph": use_graph,
             "absmax_storage": a.absmax,

@@ -47,15 +47,25 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
 // 8 weights of one packed dword: four table lookups (address = one v_perm_b32: byte k of d above the lane's replica
-// offset), scaled in fp32, rounded to fp16 (round to nearest even).
-__device__ __forceinline__ half8_t dequant8(uint32_t lbase, uint32_t d, float s) {
+// offset), then scaled in fp32 and rounded to fp16 (round to nearest even).  Two steps so that the lookups can be
+// issued ahead of other LDS reads and the arithmetic placed where their results have arrived.
+__device__ __forceinline__ void lookup8(uint32_t lbase, uint32_t d, float2_t* f) {
     uint32_t a0 = __builtin_amdgcn_perm(d, lbase, 0x03020400u), a1 = __builtin_amdgcn_perm(d, lbase, 0x03020500u);
     uint32_t a2 = __builtin_amdgcn_perm(d, lbase, 0x03020600u), a3 = __builtin_amdgcn_perm(d, lbase, 0x03020700u);
-    const float2_t f0 = *reinterpret_cast<lds_f2_t*>(a0), f1 = *reinterpret_cast<lds_f2_t*>(a1);
-    const float2_t f2 = *reinterpret_cast<lds_f2_t*>(a2), f3 = *reinterpret_cast<lds_f2_t*>(a3);
-    const half2_t h0 = __builtin_convertvector(f0 * s, half2_t), h1 = __builtin_convertvector(f1 * s, half2_t);
-    const half2_t h2 = __builtin_convertvector(f2 * s, half2_t), h3 = __builtin_convertvector(f3 * s, half2_t);
+    f[0] = *reinterpret_cast<lds_f2_t*>(a0);
+    f[1] = *reinterpret_cast<lds_f2_t*>(a1);
+    f[2] = *reinterpret_cast<lds_f2_t*>(a2);
+    f[3] = *reinterpret_cast<lds_f2_t*>(a3);
+}
+__device__ __forceinline__ half8_t scale8(const float2_t* f, float s) {
+    const half2_t h0 = __builtin_convertvector(f[0] * s, half2_t), h1 = __builtin_convertvector(f[1] * s, half2_t);
+    const half2_t h2 = __builtin_convertvector(f[2] * s, half2_t), h3 = __builtin_convertvector(f[3] * s, half2_t);
     return half8_t{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
+}
+__device__ __forceinline__ half8_t dequant8(uint32_t lbase, uint32_t d, float s) {
+    float2_t f[4];
+    lookup8(lbase, d, f);
+    return scale8(f, s);
 }
 
 __device__ __forceinline__ float act_pair(float gate_acc, float up_acc, const StageParams& sp) {
@@ -132,21 +142,29 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
     const uint32_t wlds = TG_W_OFF + wave * TG_RT * 1024 + lane * 16;
     const uint32_t slds = TG_S_OFF + wave * TG_RT * 256 + lane * 4 + (q8 ? (r & 3) : 0);
 
-    auto stage = [&](auto full_tag, int bx, int bw) {   // activations of block bx, weights and absmax of block bw
+    // DMA piece k of an iteration: pieces 0 .. TG_XI - 1 bring activations of block bx (8 tokens each), then per pair
+    // one piece for the packed weights and one for the absmax of block bw
+    constexpr int TG_PIECES = TG_XI + 2 * TG_RT;
+    auto dma_piece = [&](auto full_tag, int k, int bx, int bw) {
         constexpr bool FULL = decltype(full_tag)::value;
         const int bxc = min(bx, NB - 1), bwc = min(bw, NB - 1);
-#pragma unroll
-        for (int j = 0; j < TG_XI; j++)
-            if (FULL || 8 * (TG_XI * wave + j) < mt)
-                __builtin_amdgcn_global_load_lds((glb_void_t*)(xsrc[j] + 64 * bxc),
-                                                 (lds_void_t*)(smem + TG_X_OFF + (bx & 1) * TG_XBUF + (TG_XI * wave + j) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TG_RT; i++) {
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc[i] + (size_t)bwc * 1024),
-                                             (lds_void_t*)(smem + TG_W_OFF + (bw & 1) * TG_WBUF + (wave * TG_RT + i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(ssrc[i] + (size_t)bwc * sstride),
-                                             (lds_void_t*)(smem + TG_S_OFF + (bw & 1) * TG_SBUF + (wave * TG_RT + i) * 256), 4, 0, 0);
+        if (k < TG_XI) {
+            if (FULL || 8 * (TG_XI * wave + k) < mt)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(xsrc[k] + 64 * bxc),
+                                                 (lds_void_t*)(smem + TG_X_OFF + (bx & 1) * TG_XBUF + (TG_XI * wave + k) * 1024), 16, 0, 0);
+        } else if (k < TG_PIECES) {
+            const int i = (k - TG_XI) >> 1;
+            if ((k - TG_XI) & 1)
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(ssrc[i] + (size_t)bwc * sstride),
+                                                 (lds_void_t*)(smem + TG_S_OFF + (bw & 1) * TG_SBUF + (wave * TG_RT + i) * 256), 4, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(wsrc[i] + (size_t)bwc * 1024),
+                                                 (lds_void_t*)(smem + TG_W_OFF + (bw & 1) * TG_WBUF + (wave * TG_RT + i) * 1024), 16, 0, 0);
         }
+    };
+    auto stage = [&](auto full_tag, int bx, int bw) {
+#pragma unroll
+        for (int k = 0; k < TG_PIECES; k++) dma_piece(full_tag, k, bx, bw);
     };
     auto packed_of = [&](int bw, int i) -> u32x4_t {
         return *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t*>(wlds + (uint32_t)((bw & 1) * TG_WBUF + i * 1024));
@@ -215,7 +233,6 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
             // every DMA of the last iteration has landed (this wave's: vmcnt; the others': barrier), and nobody reads
             // what this iteration's DMA overwrites
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            stage(full_tag, b + 1, b + 2);
             uint32_t dw[TG_RT][4];   // packed block b + 1 in MFMA-step order
             float sc[TG_RT];
 #pragma unroll
@@ -231,6 +248,7 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
 #pragma unroll
             for (int t = 0; t < 4; t++) bp[t] = reinterpret_cast<lds_h8_t*>(boff[t] + xb);
             half8_t bfA[4], bfB[4];
+            float2_t lf[4];   // table values of the dword being dequantised
 #define TG_READ(BF, C)                                                                                          \
     if (FULL || (C) < ntt) {                                                                                    \
         _Pragma("unroll") for (int t = 0; t < 4; t++) TG_EXP_READ(BF[t], bp[t] + (C) * 256)                     \
@@ -240,23 +258,29 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
         _Pragma("unroll") for (int t = 0; t < 4; t++)                                                           \
             _Pragma("unroll") for (int i = 0; i < TG_RT; i++) TG_EXP_MMA(acc[i][C], a_use[i][t], BF[t])         \
     }
-            /* one dword (8 weights) of the next block per token tile and pair: parts 0..3 of pair 0 behind tiles */ \
-            /* 0, 2, 4, 6; of pair 1 behind tiles 1, 3, 5, 7 */
-#define TG_DEQ(C)                                                                                               \
-    TG_EXP_DEQ(if (((C) & 1) < TG_RT) a_fill[(C) & 1][(C) >> 1] = dequant8(lbase, dw[(C) & 1][(C) >> 1], sc[(C) & 1]);) \
-    TG_EXP_DEQ(if (TG_RT == 1 && ((C) & 1)) {})
+            /* One dword (8 weights) of the next block per token tile and pair: parts 0..3 of pair 0 with tiles 0, 2, 4, */ \
+            /* 6; of pair 1 with tiles 1, 3, 5, 7.  The table lookups go out ahead of the B reads of the next token */ \
+            /* tile (LDS returns in order: waiting for them then leaves those reads in flight), the arithmetic sits */ \
+            /* among the tile's MFMAs, and one DMA piece follows each of the first tiles. */
+#define TG_LUT(C) TG_EXP_DEQ(if (((C) & 1) < TG_RT) lookup8(lbase, dw[(C) & 1][(C) >> 1], lf);)
+#define TG_MATH(C) TG_EXP_DEQ(if (((C) & 1) < TG_RT) a_fill[(C) & 1][(C) >> 1] = scale8(lf, sc[(C) & 1]);)
+#define TG_DMA(C) dma_piece(full_tag, (C), b + 1, b + 2);
 #define TG_SB __builtin_amdgcn_sched_barrier(0);   /* keeps the order: reads of tile c + 1, then MFMAs of tile c */
             TG_SB TG_READ(bfA, 0)
-            TG_SB TG_READ(bfB, 1) TG_SB TG_MMA(bfA, 0) TG_DEQ(0)
-            TG_SB TG_READ(bfA, 2) TG_SB TG_MMA(bfB, 1) TG_DEQ(1)
-            TG_SB TG_READ(bfB, 3) TG_SB TG_MMA(bfA, 2) TG_DEQ(2)
-            TG_SB TG_READ(bfA, 4) TG_SB TG_MMA(bfB, 3) TG_DEQ(3)
-            TG_SB TG_READ(bfB, 5) TG_SB TG_MMA(bfA, 4) TG_DEQ(4)
-            TG_SB TG_READ(bfA, 6) TG_SB TG_MMA(bfB, 5) TG_DEQ(5)
-            TG_SB TG_READ(bfB, 7) TG_SB TG_MMA(bfA, 6) TG_DEQ(6)
-            TG_SB TG_MMA(bfB, 7) TG_DEQ(7) TG_SB
+            TG_SB TG_LUT(0) TG_READ(bfB, 1) TG_SB TG_MMA(bfA, 0) TG_MATH(0) TG_DMA(0)
+            TG_SB TG_LUT(1) TG_READ(bfA, 2) TG_SB TG_MMA(bfB, 1) TG_MATH(1) TG_DMA(1)
+            TG_SB TG_LUT(2) TG_READ(bfB, 3) TG_SB TG_MMA(bfA, 2) TG_MATH(2) TG_DMA(2)
+            TG_SB TG_LUT(3) TG_READ(bfA, 4) TG_SB TG_MMA(bfB, 3) TG_MATH(3) TG_DMA(3)
+            TG_SB TG_LUT(4) TG_READ(bfB, 5) TG_SB TG_MMA(bfA, 4) TG_MATH(4) TG_DMA(4)
+            TG_SB TG_LUT(5) TG_READ(bfA, 6) TG_SB TG_MMA(bfB, 5) TG_MATH(5) TG_DMA(5)
+            TG_SB TG_LUT(6) TG_READ(bfB, 7) TG_SB TG_MMA(bfA, 6) TG_MATH(6) TG_DMA(6)
+            TG_SB TG_LUT(7) TG_SB TG_MMA(bfB, 7) TG_MATH(7) TG_DMA(7)
+            _Pragma("unroll") for (int k = 8; k < TG_PIECES; k++) dma_piece(full_tag, k, b + 1, b + 2);
+            TG_SB
+#undef TG_LUT
+#undef TG_MATH
+#undef TG_DMA
 #undef TG_SB
-#undef TG_DEQ
 #undef TG_READ
 #undef TG_MMA
         };
