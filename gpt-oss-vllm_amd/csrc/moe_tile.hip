@@ -232,7 +232,11 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
         auto iteration = [&](int b, half8_t (*a_use)[4], half8_t (*a_fill)[4]) {
             // every DMA of the last iteration has landed (this wave's: vmcnt; the others': barrier), and nobody reads
             // what this iteration's DMA overwrites
+#ifdef TG_EXP_NOBARRIER
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
             uint32_t dw[TG_RT][4];   // packed block b + 1 in MFMA-step order
             float sc[TG_RT];
 #pragma unroll
@@ -258,13 +262,18 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
         _Pragma("unroll") for (int t = 0; t < 4; t++)                                                           \
             _Pragma("unroll") for (int i = 0; i < TG_RT; i++) TG_EXP_MMA(acc[i][C], a_use[i][t], BF[t])         \
     }
-            /* One dword (8 weights) of the next block per token tile and pair: parts 0..3 of pair 0 with tiles 0, 2, 4, */ \
-            /* 6; of pair 1 with tiles 1, 3, 5, 7.  The table lookups go out ahead of the B reads of the next token */ \
+            /* One dword (8 weights) of the next block per token tile and pair: parts 0..3 of pair 0 with tiles 1, 3, 5, */ \
+            /* 7 (tile 0 starts as soon as its B fragments are there); of a second pair with tiles 0, 2, 4, 6.  The table lookups go out ahead of the B reads of the next token */ \
             /* tile (LDS returns in order: waiting for them then leaves those reads in flight), the arithmetic sits */ \
             /* among the tile's MFMAs, and one DMA piece follows each of the first tiles. */
-#define TG_LUT(C) TG_EXP_DEQ(if (((C) & 1) < TG_RT) lookup8(lbase, dw[(C) & 1][(C) >> 1], lf);)
-#define TG_MATH(C) TG_EXP_DEQ(if (((C) & 1) < TG_RT) a_fill[(C) & 1][(C) >> 1] = scale8(lf, sc[(C) & 1]);)
+#define TG_PAIR(C) (TG_RT == 1 ? 0 : 1 - ((C) & 1))
+#define TG_LUT(C) TG_EXP_DEQ(if (TG_RT == 2 || ((C) & 1)) lookup8(lbase, dw[TG_PAIR(C)][(C) >> 1], lf);)
+#define TG_MATH(C) TG_EXP_DEQ(if (TG_RT == 2 || ((C) & 1)) a_fill[TG_PAIR(C)][(C) >> 1] = scale8(lf, sc[TG_PAIR(C)]);)
+#ifdef TG_EXP_NODMA
+#define TG_DMA(C)
+#else
 #define TG_DMA(C) dma_piece(full_tag, (C), b + 1, b + 2);
+#endif
 #define TG_SB __builtin_amdgcn_sched_barrier(0);   /* keeps the order: reads of tile c + 1, then MFMAs of tile c */
             TG_SB TG_READ(bfA, 0)
             TG_SB TG_LUT(0) TG_READ(bfB, 1) TG_SB TG_MMA(bfA, 0) TG_MATH(0) TG_DMA(0)
@@ -278,6 +287,7 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
             _Pragma("unroll") for (int k = 8; k < TG_PIECES; k++) dma_piece(full_tag, k, b + 1, b + 2);
             TG_SB
 #undef TG_LUT
+#undef TG_PAIR
 #undef TG_MATH
 #undef TG_DMA
 #undef TG_SB

@@ -27,14 +27,24 @@ for leg, tr_file in traces:
       for a, b in (("_ZN4m35522moe_gemm_stream_kernelILi0E", "moe_gemm_stream<gate_up,pairs="), ("_ZN4m35522moe_gemm_stream_kernelILi1E", "moe_gemm_stream<down,pairs=")):
           if short.startswith(a):
               short = b + short[len(a) + 2] + ">"
+      for a, b in (("_ZN4m35520moe_tile_gemm_kernelILi0E", "moe_tile_gemm<gate_up>"), ("_ZN4m35520moe_tile_gemm_kernelILi1E", "moe_tile_gemm<down>")):
+          if short.startswith(a):
+              short = b
+      short = short.replace("_ZN4m35516moe_route_kernelE", "moe_route")
       short = short.replace("_ZN4m35524paged_attn_decode_kernelE", "paged_attn_decode").replace("_ZN4m35518router_topk_kernelE", "router_topk")
       short = short.replace("_ZN4m35518moe_combine_kernelE", "moe_combine").split("PK")[0].split("EPK")[0]
       key = (leg, short, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Workgroup_Size_X"]), int(r["LDS_Block_Size"]),
              int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]))
       groups[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 
+tile_pmc = collections.defaultdict(list)
+for f in glob.glob(f"{src}/pmc_tile_*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "moe_tile" in r["Kernel_Name"]:
+            tile_pmc[("gate_up" if "ILi0E" in r["Kernel_Name"] else "down", r["Counter_Name"])].append(float(r["Counter_Value"]))
+
 pmc = collections.defaultdict(list)
-for f in glob.glob(f"{src}/pmc_*/*/*counter_collection.csv"):
+for f in glob.glob(f"{src}/pmc_rd/*/*counter_collection.csv") + glob.glob(f"{src}/pmc_fetch/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         if "moe_gemm" in r["Kernel_Name"]:
             pmc[("gate_up" if "ILi0E" in r["Kernel_Name"] else "down", r["Counter_Name"])].append(float(r["Counter_Value"]))
@@ -42,7 +52,9 @@ for f in glob.glob(f"{src}/pmc_*/*/*counter_collection.csv"):
 bench = json.load(open(f"{src}/bench_line.json"))
 with open(f"profiles/{tag}_summary.md", "w") as out:
     out.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bs1 [--batch-per-gpu 1]`\n\n")
-    out.write("Two runs: the default workload (bs=32 per GPU) and `--batch-per-gpu 1`; both with `--no-bs1` so a row is one configuration.\n\n")
+    out.write("Two runs: the default workload (bs=32 per GPU) and `--batch-per-gpu 1`; both with `--no-bs1` so a row is one configuration. "
+              "Each run ends with the 8192-token prefill leg: its launches are the rows with 8192 workgroups (router, combine), "
+              "moe_route and moe_tile_gemm.\n\n")
     out.write("| leg | kernel | workgroups | threads | launches | avg us | min us | max us |\n|---|---|---|---|---|---|---|---|\n")
     for k, v in sorted(groups.items()):
         out.write(f"| {k[0]} | {k[1]} | {k[2]} | {k[3]} | {len(v)} | {sum(v) / len(v) / 1e3:.2f} | {min(v) / 1e3:.2f} | {max(v) / 1e3:.2f} |\n")
@@ -54,6 +66,18 @@ with open(f"profiles/{tag}_summary.md", "w") as out:
             out.write(f"| {k[0]} | {k[1]} | {len(v)} | {sum(v) / len(v):.6g} |\n")
         out.write("\nTCC_EA0_RDREQ counts 128-byte requests here (no 32-byte ones); FETCH_SIZE is in KiB and reads one half of a "
                   "wide coalesced stream on gfx950, so bytes = 2 x FETCH_SIZE x 1024 = RDREQ x 128.\n")
+if tile_pmc:
+    with open(f"profiles/{tag}_summary.md", "a") as out:
+        out.write("\n## Matrix-core counters of the tile kernel (separate --pmc passes over scratch/prof_tile.py: 8192 tokens, 32 experts, per launch)\n\n")
+        out.write("| kernel | counter | launches | mean |\n|---|---|---|---|\n")
+        for k, v in sorted(tile_pmc.items()):
+            out.write(f"| {k[0]} | {k[1]} | {len(v)} | {sum(v) / len(v):.6g} |\n")
+        for kern in ("gate_up", "down"):
+            busy, act = tile_pmc.get((kern, "SQ_VALU_MFMA_BUSY_CYCLES")), tile_pmc.get((kern, "GRBM_GUI_ACTIVE"))
+            if busy and act:
+                cyc = sum(act) / len(act) / 8          # the counter sums the 8 XCDs
+                out.write(f"\n{kern}: matrix cores busy {sum(busy) / len(busy) / (1024 * cyc):.3f} of the cycles of the launch "
+                          f"(SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 = {cyc:.4g} cycles)).\n")
 rd = pmc.get(("gate_up", "TCC_EA0_RDREQ_sum"))
 rd_down = pmc.get(("down", "TCC_EA0_RDREQ_sum"))
 if rd:

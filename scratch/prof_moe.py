@@ -11,9 +11,9 @@ layers=[]
 for l in range(L):
     layers.append(dict(
         w13_q=torch.randint(0,256,(E,FF*H),dtype=torch.uint8,device=d,generator=g),
-        w13_a=torch.rand((E,2*FF*H//64),device=d,generator=g)*0.03,
+        w13_a=(torch.randint(0,256,(E,2*FF*H//64),dtype=torch.uint8,device=d,generator=g), torch.rand((E,256),device=d,generator=g)*0.03),
         w2_q=torch.randint(0,256,(E,H*FF//2),dtype=torch.uint8,device=d,generator=g),
-        w2_a=torch.rand((E,H*FF//64),device=d,generator=g)*0.03,
+        w2_a=(torch.randint(0,256,(E,H*FF//64),dtype=torch.uint8,device=d,generator=g), torch.rand((E,256),device=d,generator=g)*0.03),
         wr=(torch.randn((E,H),device=d,generator=g)*0.02).half(),
         x=torch.randn((B,H),device=d,generator=g).half()))
 ws=torch.empty(lib.moe_workspace_bytes(B,k,H,FF,E),dtype=torch.uint8,device=d)

@@ -10,4 +10,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun
 grep '^{' gpurun_out/prof_${tag}_bench_bs1.log > gpurun_out/prof_$tag/bench_line_bs1.json
 timeout -s KILL 120 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d gpurun_out/prof_$tag/pmc_rd -- python scratch/prof_moe.py 32 2 > gpurun_out/prof_${tag}_pmc.log 2>&1 || { tail -5 gpurun_out/prof_${tag}_pmc.log; exit 1; }
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_$tag/pmc_fetch -- python scratch/prof_moe.py 32 2 > gpurun_out/prof_${tag}_pmc2.log 2>&1 || { tail -5 gpurun_out/prof_${tag}_pmc2.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/prof_$tag/pmc_tile_sq -- python scratch/prof_tile.py 8192 2 > gpurun_out/prof_${tag}_pmc3.log 2>&1 || { tail -5 gpurun_out/prof_${tag}_pmc3.log; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d gpurun_out/prof_$tag/pmc_tile_grbm -- python scratch/prof_tile.py 8192 2 > gpurun_out/prof_${tag}_pmc4.log 2>&1 || { tail -5 gpurun_out/prof_${tag}_pmc4.log; exit 1; }
 echo done
