@@ -127,6 +127,59 @@ __global__ __launch_bounds__(ROUTER_THREADS) void router_topk_kernel(const half_
     if (wave == 0) topk_softmax_wave(logit, E, k, ids + (int64_t)t * k, w + (int64_t)t * k);
 }
 
+// Many tokens (prefill): 16 tokens per workgroup on the matrix cores, so the router matrix is read from L2 once per
+// 16 tokens instead of once per token.  logits[16 tokens][E] = x[16][H] Wr^T with v_mfma_f32_16x16x32_f16: the A
+// operand is 16 token rows (lane (r, g) loads x[token r][32 s + 8 g ..] straight from global memory), the B operand
+// 16 router rows per expert tile; the 4 waves take the 32-column steps s = wave, wave + 4, .. and their partial tiles
+// are summed through LDS in wave order; then each wave selects for 4 of the tokens.
+constexpr int ROUTER_TILE_MAX_E = 128;
+__global__ __launch_bounds__(256) void router_topk_tile_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wr,
+                                                               const half_t* __restrict__ br, int T, int H, int E, int k,
+                                                               int32_t* __restrict__ ids, float* __restrict__ w,
+                                                               half_t* __restrict__ logits_out) {
+    extern __shared__ __attribute__((aligned(16))) float part[];   // [4 waves][16 tokens][E], then logits in [0][..][..]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int t0 = blockIdx.x * 16;
+    const int nj = (E + 15) / 16;
+    const half_t* xrow = x + (int64_t)min(t0 + r, T - 1) * H + 8 * g;
+    float4_t acc[ROUTER_TILE_MAX_E / 16];
+#pragma unroll
+    for (int j = 0; j < ROUTER_TILE_MAX_E / 16; j++) acc[j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    const int steps = H / 32;
+    for (int s = wave; s < steps; s += 4) {
+        const half8_t a = *reinterpret_cast<const half8_t*>(xrow + 32 * s);
+#pragma unroll
+        for (int j = 0; j < ROUTER_TILE_MAX_E / 16; j++) {
+            if (j < nj) {
+                const half8_t b = *reinterpret_cast<const half8_t*>(wr + (int64_t)min(16 * j + r, E - 1) * H + 32 * s + 8 * g);
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    // accumulator register i of lane (r, g): token 4 g + i, expert 16 j + r
+#pragma unroll
+    for (int j = 0; j < ROUTER_TILE_MAX_E / 16; j++) {
+        if (j < nj && 16 * j + r < E) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) part[((size_t)wave * 16 + 4 * g + i) * E + 16 * j + r] = acc[j][i];
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 16 * E; idx += 256) {
+        const int e = idx % E, tok = idx / E;
+        const float full = ((part[idx] + part[16 * E + idx]) + part[32 * E + idx]) + part[48 * E + idx] + (br ? (float)br[e] : 0.f);
+        const half_t l16 = (half_t)full;   // the reference's router output is an fp16 tensor
+        part[idx] = (float)l16;
+        if (logits_out && t0 + tok < T) logits_out[(int64_t)(t0 + tok) * E + e] = l16;
+    }
+    __syncthreads();
+    for (int i = 0; i < 4; i++) {
+        const int t = t0 + 4 * wave + i;
+        if (t < T) topk_softmax_wave(part + (size_t)(4 * wave + i) * E, E, k, ids + (int64_t)t * k, w + (int64_t)t * k);
+    }
+}
+
 __global__ __launch_bounds__(256) void topk_softmax_kernel(const half_t* __restrict__ logits, int T, int E, int k,
                                                            int32_t* __restrict__ ids, float* __restrict__ w) {
     extern __shared__ __attribute__((aligned(16))) float lg[];   // [4][E]
@@ -153,6 +206,12 @@ extern "C" int m355_router_topk(const void* x_f16, const void* wr_f16, const voi
                     T, H, E, k, ROUTER_MAX_E);
     if (!aligned(x_f16, 16) || !aligned(wr_f16, 16)) return fail(-3, "m355_router_topk: x and wr must be 16-byte aligned");
     if (T == 0) return 0;
+    if (T >= 64 && E <= ROUTER_TILE_MAX_E && (H % 32) == 0) {
+        router_topk_tile_kernel<<<dim3((T + 15) / 16), dim3(256), 4 * 16 * E * sizeof(float), (hipStream_t)stream>>>(
+            (const half_t*)x_f16, (const half_t*)wr_f16, (const half_t*)br_f16, T, H, E, k, ids, w, (half_t*)logits_out_f16);
+        M355_LAUNCH_CHECK("m355_router_topk");
+        return 0;
+    }
     router_topk_kernel<<<dim3(T), dim3(ROUTER_THREADS), 0, (hipStream_t)stream>>>(
         (const half_t*)x_f16, (const half_t*)wr_f16, (const half_t*)br_f16, H, E, k, ids, w, (half_t*)logits_out_f16);
     M355_LAUNCH_CHECK("m355_router_topk");
