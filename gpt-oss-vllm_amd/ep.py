@@ -50,6 +50,9 @@ class HipOps:
     def workspace_bytes(self, T, k, H, FF, E_local):
         return self.lib.moe_workspace_bytes(T, k, H, FF, E_local)
 
+    def kernel_choice_flags(self, tokens, top_k, global_experts):
+        return self.lib.kernel_choice_flags(tokens, top_k, global_experts)
+
 
 class ExpertParallelMoE:
     """One MoE layer's expert shard plus the buffers of its token exchange (allocated once, reused)."""
@@ -72,6 +75,7 @@ class ExpertParallelMoE:
         # (a one-rank rehearsal of the multi-GPU path, needs an initialised process group)
         self.force_exchange = force_exchange and dist.is_initialized()
         self.T = max_tokens
+        self.shard_flags = self.ops.kernel_choice_flags(self.world * max_tokens, top_k, num_experts)
         dev = device if device is not None else weights[0].device
         N, T, H, k = self.world, max_tokens, hidden, top_k
         rb = self.ops.row_bytes(H, k)
@@ -101,8 +105,9 @@ class ExpertParallelMoE:
         self.ops.pack(x, ids, w, N, self.epr, self.send)
         dist.all_to_all_single(self.recv, self.send, group=self.group)
         self.ops.unpack(self.recv, N * T, k, H, self.x_all, self.ids_all, self.w_all)
+        # this rank sees the N * T token slots of all ranks but only the pairs routed to its experts
         self.ops.moe(self.x_all, self.ids_all, self.w_all, self.weights, self.epr, self.e_first, H, self.FF,
-                     self.workspace, self.partial, self.flags)
+                     self.workspace, self.partial, self.flags | self.shard_flags)
         dist.all_to_all_single(self.back.view(-1), self.partial.view(-1), group=self.group)
         self.ops.reduce(self.back, N, T, H, out)
         return out

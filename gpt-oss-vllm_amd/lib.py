@@ -167,6 +167,17 @@ def moe_workspace_bytes(T: int, k: int, H: int, FF: int, E_local: int) -> int:
     return int(load().m355_moe_workspace_bytes(T, k, H, FF, E_local))
 
 
+TILE_MIN_MEAN_PAIRS = 40   # the library's own crossover between its two MoE GEMM kernels (csrc/moe.hip)
+
+
+def kernel_choice_flags(tokens: int, top_k: int, global_experts: int) -> int:
+    """The library chooses between its two GEMM kernels from tokens * top_k / E_local, which is right when every
+    expert is local.  A rank that holds a shard sees the tokens of all ranks but only its share of the pairs: there
+    the caller, who knows the global expert count, fixes the choice with this flag."""
+    many = tokens > 16 and tokens * top_k >= TILE_MIN_MEAN_PAIRS * global_experts
+    return FLAG_FORCE_TILE if many else FLAG_FORCE_STREAM
+
+
 def moe_nf4_forward(x, ids, w, w13_q, w13_absmax, w2_q, w2_absmax, *, E_local: int, e_first: int, H: int, FF: int,
                     workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                     act_mode: int = ACT_SILU_CONCAT, flags: int = FLAG_FP16_COMBINE,

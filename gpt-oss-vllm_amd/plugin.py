@@ -385,6 +385,9 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
             owned = torch.nonzero(expert_map >= 0).flatten()
             e_first = int(owned[0].item()) if owned.numel() else 0
         T = x2.shape[0]
+        flags = lib.FLAG_FP16_COMBINE
+        if expert_map is not None and global_num_experts > 0:     # a shard: see lib.kernel_choice_flags
+            flags |= lib.kernel_choice_flags(T, top_k, global_num_experts)
         ws = layer._m355_ws.get(T)
         if ws is None:
             ws = torch.empty(max(256, lib.moe_workspace_bytes(T, top_k, H, FF, E)), dtype=torch.uint8, device=x2.device)
@@ -395,7 +398,7 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
             a2 = (layer._m355_codes["w2"], layer._m355_tables["w2"])
         out = lib.moe_nf4_forward(x2.contiguous(), ids, w, layer.w13_qweight.data, a13,
                                   layer.w2_qweight.data, a2, E_local=E, e_first=e_first, H=H, FF=FF,
-                                  workspace=ws, act_mode=act_mode, b13=getattr(layer, "_m355_b13", None),
+                                  workspace=ws, act_mode=act_mode, flags=flags, b13=getattr(layer, "_m355_b13", None),
                                   b2=getattr(layer, "_m355_b2", None))
         if in_dtype != torch.float16:
             out = out.to(in_dtype)

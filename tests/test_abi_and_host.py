@@ -128,3 +128,12 @@ def test_router_cast_helper():
     blk.router = torch.nn.Linear(8, 4).to(torch.bfloat16)
     plugin.cast_router_to_fp16(blk)
     assert blk.router.weight.dtype == torch.float16 and blk.router.bias.dtype == torch.float16
+
+
+def test_kernel_choice_for_expert_shards():
+    """A shard sees every rank's token slots but only its share of the pairs: the choice follows the global count."""
+    from gpt_oss_vllm_amd import lib
+    assert lib.kernel_choice_flags(256, 4, 32) == lib.FLAG_FORCE_STREAM      # 8 ranks x 32 tokens: 32 pairs per expert
+    assert lib.kernel_choice_flags(8192, 4, 32) == lib.FLAG_FORCE_TILE
+    assert lib.kernel_choice_flags(8192, 4, 128) == lib.FLAG_FORCE_TILE
+    assert lib.kernel_choice_flags(16, 32, 4) == lib.FLAG_FORCE_STREAM        # a token tile of <= 16 never takes the tile kernel

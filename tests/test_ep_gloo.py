@@ -23,6 +23,10 @@ class CpuOps:
     def workspace_bytes(self, *a):
         return 0
 
+    def kernel_choice_flags(self, tokens, top_k, global_experts):
+        from gpt_oss_vllm_amd import lib      # host arithmetic only: nothing is loaded
+        return lib.kernel_choice_flags(tokens, top_k, global_experts)
+
     def pack(self, x, ids, w, n_ranks, epr, send):
         T_, k = ids.shape
         rb = self.row_bytes(x.shape[1], k)
@@ -56,7 +60,7 @@ class CpuOps:
         o = self.ref.moe_forward(x.numpy(), np.where(ids.numpy() < 0, 10 ** 6, ids.numpy()).astype(np.int32), w.numpy(),
                                  w13_q=self.layer["w13_q"][sl], w13_absmax=self.layer["w13_absmax"][sl],
                                  w2_q=self.layer["w2_q"][sl], w2_absmax=self.layer["w2_absmax"][sl], E_local=E_local,
-                                 e_first=e_first, H=H_, FF=FF_, flags=flags)
+                                 e_first=e_first, H=H_, FF=FF_, flags=flags & 1)   # the kernel-choice bits mean nothing to the oracle
         out.copy_(torch.from_numpy(o))
 
     def reduce(self, recv, n_ranks, T_, H_, out):
