@@ -59,8 +59,11 @@ class ExpertParallelMoE:
 
     def __init__(self, weights, *, num_experts: int, top_k: int, hidden: int, ffn: int, max_tokens: int,
                  group: Optional[dist.ProcessGroup] = None, ops=None, device=None, flags: int = 1,
-                 force_exchange: bool = False):
+                 force_exchange: bool = False, exchange=None):
         self.group = group
+        # exchange(recv, send): the all-to-all of equal chunks.  Default: torch.distributed (RCCL on device tensors).
+        self.exchange = exchange if exchange is not None else (
+            lambda recv, send: dist.all_to_all_single(recv, send, group=self.group))
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         if num_experts % self.world:
@@ -103,11 +106,11 @@ class ExpertParallelMoE:
             self.ops.moe(x, ids, w, self.weights, self.epr, 0, H, self.FF, self.workspace, out, self.flags)
             return out
         self.ops.pack(x, ids, w, N, self.epr, self.send)
-        dist.all_to_all_single(self.recv, self.send, group=self.group)
+        self.exchange(self.recv, self.send)
         self.ops.unpack(self.recv, N * T, k, H, self.x_all, self.ids_all, self.w_all)
         # this rank sees the N * T token slots of all ranks but only the pairs routed to its experts
         self.ops.moe(self.x_all, self.ids_all, self.w_all, self.weights, self.epr, self.e_first, H, self.FF,
                      self.workspace, self.partial, self.flags | self.shard_flags)
-        dist.all_to_all_single(self.back.view(-1), self.partial.view(-1), group=self.group)
+        self.exchange(self.back.view(-1), self.partial.view(-1))
         self.ops.reduce(self.back, N, T, H, out)
         return out

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -107,3 +108,66 @@ def test_expert_parallel_exchange_world2():
         assert p.exitcode == 0
     for rank, err, mx in res:
         assert err <= 2e-3 * mx + 1e-6, (rank, err, mx)
+
+
+# ------------------------------------------------------------------------------------------------
+# Two ranks with the real HIP kernels on ONE GPU (the test box has one): RCCL refuses two ranks on one device, so the
+# chunks travel through host memory over gloo; everything else (pack, unpack, sharded experts with e_first != 0,
+# reduce) is the product's device code.
+def _gpu_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import ref
+    import gpt_oss_vllm_amd  # noqa: F401
+    from gpt_oss_vllm_amd import ep, lib
+    dev = torch.device("cuda:0")
+    Hg, FFg, Eg, Kg, Tg = 256, 192, 8, 3, 21
+    layer = ref.synth_layer(78, Eg, Hg, FFg)
+    epr = Eg // world
+    sl = slice(rank * epr, (rank + 1) * epr)
+    tiles = []
+    for e in range(rank * epr, (rank + 1) * epr):
+        q13, a13 = lib.repack_nf4(torch.from_numpy(layer["w13_q"][e]).to(dev), torch.from_numpy(layer["w13_absmax"][e]).to(dev), 2 * FFg, Hg)
+        q2, a2 = lib.repack_nf4(torch.from_numpy(layer["w2_q"][e]).to(dev), torch.from_numpy(layer["w2_absmax"][e]).to(dev), Hg, FFg)
+        tiles.append((q13, a13, q2, a2))
+    weights = tuple(torch.stack([t[i] for t in tiles]) for i in range(4))
+
+    def staged(recv, send):
+        r = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(r, send.cpu())
+        recv.copy_(r)
+
+    x = ref.normal_f16(ref.stream_seed(300, rank), (Tg, Hg))
+    lg = ref.normal_f16(ref.stream_seed(400, rank), (Tg, Eg), 1.5)
+    ids, w, _ = ref.router_topk(lg, np.eye(Eg, dtype=np.float16), None, Kg)
+    moe = ep.ExpertParallelMoE(weights, num_experts=Eg, top_k=Kg, hidden=Hg, ffn=FFg, max_tokens=Tg, device=dev, exchange=staged)
+    out = moe.forward(torch.from_numpy(x).to(dev), torch.from_numpy(ids).to(dev), torch.from_numpy(w).to(dev))
+    torch.cuda.synchronize()
+    want = ref.moe_forward(x, ids, w, **layer, E_local=Eg, H=Hg, FF=FFg).astype(np.float32)
+    err = float(np.abs(out.float().cpu().numpy() - want).max())
+    q.put((rank, err, float(np.abs(want).max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_expert_parallel_two_ranks_one_gpu():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, mx in res:
+        # partial rows travel as fp16 and are summed over ranks in fp32: tolerance of the GEMM plus one fp16 rounding
+        assert err <= 3e-3 * mx + 1e-5, (rank, err, mx)
