@@ -133,6 +133,8 @@ __global__ __launch_bounds__(ROUTER_THREADS) void router_topk_kernel(const half_
 // 16 router rows per expert tile; the 4 waves take the 32-column steps s = wave, wave + 4, .. and their partial tiles
 // are summed through LDS in wave order; then each wave selects for 4 of the tokens.
 constexpr int ROUTER_TILE_MAX_E = 128;
+constexpr int ROUTER_TILE_MIN_T = 1024;   // below, one workgroup per token is faster (few workgroups of 16 tokens are latency-bound)
+template <int NJ>   // expert tiles of 16 (E <= 16 NJ)
 __global__ __launch_bounds__(256) void router_topk_tile_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wr,
                                                                const half_t* __restrict__ br, int T, int H, int E, int k,
                                                                int32_t* __restrict__ ids, float* __restrict__ w,
@@ -141,26 +143,35 @@ __global__ __launch_bounds__(256) void router_topk_tile_kernel(const half_t* __r
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int t0 = blockIdx.x * 16;
-    const int nj = (E + 15) / 16;
     const half_t* xrow = x + (int64_t)min(t0 + r, T - 1) * H + 8 * g;
-    float4_t acc[ROUTER_TILE_MAX_E / 16];
+    float4_t acc[NJ];
 #pragma unroll
-    for (int j = 0; j < ROUTER_TILE_MAX_E / 16; j++) acc[j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; j++) acc[j] = float4_t{0.f, 0.f, 0.f, 0.f};
     const int steps = H / 32;
-    for (int s = wave; s < steps; s += 4) {
-        const half8_t a = *reinterpret_cast<const half8_t*>(xrow + 32 * s);
+    // several 32-column steps per round, every load of the round requested before the first MFMA
+    constexpr int U = NJ <= 2 ? 6 : (NJ <= 4 ? 4 : 2);
+    for (int s0 = wave; s0 < steps; s0 += 4 * U) {
+        half8_t a[U], b[U][NJ];
 #pragma unroll
-        for (int j = 0; j < ROUTER_TILE_MAX_E / 16; j++) {
-            if (j < nj) {
-                const half8_t b = *reinterpret_cast<const half8_t*>(wr + (int64_t)min(16 * j + r, E - 1) * H + 32 * s + 8 * g);
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[j], 0, 0, 0);
+        for (int u = 0; u < U; u++) {
+            const int s = min(s0 + 4 * u, steps - 1);
+            a[u] = *reinterpret_cast<const half8_t*>(xrow + 32 * s);
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+                b[u][j] = *reinterpret_cast<const half8_t*>(wr + (int64_t)min(16 * j + r, E - 1) * H + 32 * s + 8 * g);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (s0 + 4 * u < steps) {
+#pragma unroll
+                for (int j = 0; j < NJ; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b[u][j], acc[j], 0, 0, 0);
             }
         }
     }
     // accumulator register i of lane (r, g): token 4 g + i, expert 16 j + r
 #pragma unroll
-    for (int j = 0; j < ROUTER_TILE_MAX_E / 16; j++) {
-        if (j < nj && 16 * j + r < E) {
+    for (int j = 0; j < NJ; j++) {
+        if (16 * j + r < E) {
 #pragma unroll
             for (int i = 0; i < 4; i++) part[((size_t)wave * 16 + 4 * g + i) * E + 16 * j + r] = acc[j][i];
         }
@@ -206,9 +217,18 @@ extern "C" int m355_router_topk(const void* x_f16, const void* wr_f16, const voi
                     T, H, E, k, ROUTER_MAX_E);
     if (!aligned(x_f16, 16) || !aligned(wr_f16, 16)) return fail(-3, "m355_router_topk: x and wr must be 16-byte aligned");
     if (T == 0) return 0;
-    if (T >= 64 && E <= ROUTER_TILE_MAX_E && (H % 32) == 0) {
-        router_topk_tile_kernel<<<dim3((T + 15) / 16), dim3(256), 4 * 16 * E * sizeof(float), (hipStream_t)stream>>>(
-            (const half_t*)x_f16, (const half_t*)wr_f16, (const half_t*)br_f16, T, H, E, k, ids, w, (half_t*)logits_out_f16);
+    if (T >= ROUTER_TILE_MIN_T && E <= ROUTER_TILE_MAX_E && (H % 32) == 0) {
+        const dim3 grid((T + 15) / 16), block(256);
+        const size_t lds = 4 * 16 * E * sizeof(float);
+        hipStream_t st = (hipStream_t)stream;
+#define M355_ROUTER_TILE(NJ)                                                                                          \
+    router_topk_tile_kernel<NJ><<<grid, block, lds, st>>>((const half_t*)x_f16, (const half_t*)wr_f16, (const half_t*)br_f16, \
+                                                          T, H, E, k, ids, w, (half_t*)logits_out_f16)
+        if (E <= 16) M355_ROUTER_TILE(1);
+        else if (E <= 32) M355_ROUTER_TILE(2);
+        else if (E <= 64) M355_ROUTER_TILE(4);
+        else M355_ROUTER_TILE(8);
+#undef M355_ROUTER_TILE
         M355_LAUNCH_CHECK("m355_router_topk");
         return 0;
     }

@@ -30,7 +30,8 @@ for leg, tr_file in traces:
       for a, b in (("_ZN4m35520moe_tile_gemm_kernelILi0E", "moe_tile_gemm<gate_up>"), ("_ZN4m35520moe_tile_gemm_kernelILi1E", "moe_tile_gemm<down>")):
           if short.startswith(a):
               short = b
-      short = short.replace("_ZN4m35516moe_route_kernelE", "moe_route")
+      short = short.replace("_ZN4m35516moe_route_kernelE", "moe_route").replace("_ZN4m35523router_topk_tile_kernelE", "router_topk_tile")
+      short = short.replace("m355::moe_route_kernel", "moe_route")
       short = short.replace("_ZN4m35524paged_attn_decode_kernelE", "paged_attn_decode").replace("_ZN4m35518router_topk_kernelE", "router_topk")
       short = short.replace("_ZN4m35518moe_combine_kernelE", "moe_combine").split("PK")[0].split("EPK")[0]
       key = (leg, short, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Workgroup_Size_X"]), int(r["LDS_Block_Size"]),

@@ -99,7 +99,7 @@ def test_repack_layout(ref, m355, cuda):
 
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("T,E,k,bias", [(1, 32, 4, False), (32, 32, 4, True), (7, 128, 4, False), (3, 8, 2, True),
-                                        (200, 32, 4, True), (77, 128, 4, False), (64, 40, 3, True)])   # T >= 64: 16 tokens per workgroup
+                                        (1100, 32, 4, True), (1030, 128, 4, False), (1024, 40, 3, True)])   # T >= 1024: 16 tokens per workgroup
 def test_router_vs_oracle(T, E, k, bias, ref, m355, cuda):
     H = 2880
     x = ref.normal_f16(ref.stream_seed(T, E, 1), (T, H))
