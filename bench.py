@@ -294,7 +294,7 @@ def full_layer_leg(lib, main_step, batch, ctx, layers, device, steps, warmup):
 
 
 def prefill_leg(lib, main_step, device, tokens, reps=3):
-    """The same experts fed a prefill-sized batch (BASELINE configs[4] is an 8k-token prefill): per layer router top-k
+    """The same experts fed a prefill-sized batch (configs[4] of BASELINE.json is an 8k-token prefill): per layer router top-k
     + fused NF4 MoE, where the library picks its kernel for many tokens per expert (256-token tiles, weights
     dequantised once per tile, MFMA-bound).  Attention prefill is not part of the path built here.  The MFMA figure
     times the gate_up launches alone (one HIP graph of all layers, HIP events on the launch stream)."""
@@ -465,7 +465,7 @@ def main():
     }
 
     if not a.no_bs1:
-        # BASELINE configs[1]: bs=1 greedy decode, seq_len 256 (per GPU when N > 1)
+        # configs[1] of BASELINE.json: bs=1 greedy decode, seq_len 256 (per GPU when N > 1)
         del main_step.graph
         main_step.graph = None
         bs1 = DecodeStep(lib, ep_mod, 1, a.ctx, a.layers, rank, world, device, weights_from=main_step,
