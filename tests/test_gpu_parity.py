@@ -195,7 +195,8 @@ def test_moe_expert_shards_sum_to_whole(ref, m355, cuda):
     _close(whole.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("T,E,k", [(150, 8, 2), (5, 160, 4), (64, 32, 4), (65, 32, 4), (3, 8, 2), (4, 160, 4)])
+@pytest.mark.parametrize("T,E,k", [(150, 8, 2), (5, 160, 4), (64, 32, 4), (65, 32, 4), (3, 8, 2), (4, 160, 4),
+                                   (200, 8, 2), (300, 6, 3)])   # the last two: 50 and 150 pairs per expert, the tile kernel
 def test_moe_routing_paths_vs_oracle(T, E, k, ref, m355, cuda):
     """Pairs are bucketed inside the gate_up launch up to 256 pairs / 128 local experts and by the routing kernel
     beyond that: both sides of each limit against the oracle, and the stage-by-stage call (route, gate_up, down,
