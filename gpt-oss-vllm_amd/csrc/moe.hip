@@ -21,6 +21,7 @@
 // replicated 32x in LDS (entry address = (byte*32 + lane%32)*4) so a wave's lookups never collide on a bank.
 // The code values are fp16-rounded NF4 entries; scales stay fp32.
 #include "moe_shared.h"
+#include "router_shared.h"
 
 namespace m355 {
 
@@ -366,7 +367,15 @@ struct RouteIO {
     const int32_t* ids;
     int P, E_local, e_first;
     int32_t *n_active, *offsets, *active, *sorted, *inv, *n_tiles, *tile_expert, *tile_m0;
+    // INLINE == 2: the launch also computes the router (logits, top-k, softmax) for its few tokens, every workgroup
+    // for itself; workgroup 0 leaves ids and weights in ids_out / w_out for the combine
+    const half_t *r_x, *r_wr, *r_br;
+    int r_H, r_E, r_k;
+    int32_t* ids_out;
+    float* w_out;
 };
+constexpr int FUSE_ROUTER_MAX_T = 8;     // tokens up to which gate_up computes the router itself
+constexpr int FUSE_ROUTER_MAX_E = 256;   // global experts: the logits of all tokens must fit the reduction buffers
 constexpr int INLINE_MAX_P = 256;      // one pair per thread of the smallest workgroup
 constexpr int INLINE_MAX_E = 128;      // two experts per lane of the scanning wave
 constexpr int INLINE_MAX_TILES = 160;  // <= min(P, E) when T <= 16, else <= E + P / 16
@@ -469,7 +478,7 @@ __device__ __forceinline__ void build_lutp(uint32_t* lut, unsigned char* park, i
     lds_barrier();   // park is free again: everyone is done reading the codes
 }
 
-template <int MODE, int PAIRS, bool INLINE>
+template <int MODE, int PAIRS, int INLINE>   // INLINE 0: routing lists from the workspace, 1: pairs bucketed here, 2: router too
 __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     const half_t* __restrict__ xin, const uint8_t* __restrict__ wq, const float* __restrict__ wam,
     const int32_t* __restrict__ n_tiles, const int32_t* __restrict__ tile_expert, const int32_t* __restrict__ tile_m0,
@@ -486,7 +495,28 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     if constexpr (INLINE) {
         // the ids are requested first; the code table is built later, while the first weights are on their way
         int my_e = -1;
-        if ((int)threadIdx.x < rio.P) my_e = rio.ids[threadIdx.x] - rio.e_first;
+        if constexpr (INLINE == 2) {
+            // router of the launch's few tokens, computed by every workgroup with the router kernel's own code (same
+            // bits): logits [T][E] and the picks live in the reduction buffers until the pairs are bucketed
+            const int Tn = rio.P / rio.r_k;
+            float* lg = reinterpret_cast<float*>(red);
+            float* wl = lg + Tn * rio.r_E;
+            int32_t* il = reinterpret_cast<int32_t*>(wl + rio.P);
+            for (int t = 0; t < Tn; t++)
+                router_logits_wg<PAIRS * 4>(rio.r_x + (int64_t)t * rio.r_H, rio.r_wr, rio.r_br, rio.r_H, rio.r_E, lg + t * rio.r_E, nullptr);
+            __syncthreads();
+            for (int t = threadIdx.x >> 6; t < Tn; t += PAIRS * 4) topk_softmax_wave(lg + t * rio.r_E, rio.r_E, rio.r_k, il + t * rio.r_k, wl + t * rio.r_k);
+            __syncthreads();
+            if ((int)threadIdx.x < rio.P) {
+                my_e = il[threadIdx.x] - rio.e_first;
+                if (blockIdx.x == 0) {
+                    rio.ids_out[threadIdx.x] = il[threadIdx.x];
+                    rio.w_out[threadIdx.x] = wl[threadIdx.x];
+                }
+            }
+        } else {
+            if ((int)threadIdx.x < rio.P) my_e = rio.ids[threadIdx.x] - rio.e_first;
+        }
         if (my_e >= rio.E_local) my_e = -1;
         inline_route(rio, my_e, mt_rows, reinterpret_cast<uint32_t*>(red), rt, threadIdx.x, THREADS);
     } else {
@@ -775,12 +805,14 @@ static int device_setup(int dev, int* cus) {
     if (!done[d]) {
         if (int rc = allow_big_lds(&moe_gemm_kernel<0>)) return rc;
         if (int rc = allow_big_lds(&moe_gemm_kernel<1>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1, false>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2, false>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1, true>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2, true>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 1, false>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 2, false>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1, 0>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2, 0>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1, 1>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2, 1>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1, 2>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2, 2>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 1, 0>)) return rc;
+        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 2, 0>)) return rc;
         int v = 0;
         if (int rc = hip_status(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute")) return rc;
         ncu[d] = v > 0 ? v : 256;
@@ -802,7 +834,7 @@ static int tile_gemm_device_setup_once(int dev) {
 // mean (token, k) pairs per local expert from which the tile kernel takes over
 constexpr int TILE_MIN_MEAN_PAIRS = 40;   // measured crossover on gpt-oss-20b shapes (32 experts: about 320 tokens)
 
-static int stream_lds_bytes(int pairs, bool inline_route) {   // (activations live in registers)
+static int stream_lds_bytes(int pairs, int inline_route) {   // (activations live in registers)
     return LUTP_BYTES + 2 * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4 + (inline_route ? (int)align_up(sizeof(InlineTables), 16) : 0);
 }
 
@@ -813,7 +845,7 @@ static bool can_route_inline(int P, int E_local, int K) {
 
 // W [R][K] per expert.  K <= 48 blocks: streaming kernel, one or two workgroups per CU; else the general kernel.
 // `rio` non-null (gate_up only): the kernel buckets the pairs itself and leaves the lists in the workspace.
-template <int MODE, bool INLINE>
+template <int MODE, int INLINE>
 static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, const MoeWorkspace& ws, int K, int R,
                        int k_top, int mt_rows, int slots, half_t* outp, int cus, hipStream_t st, const RouteIO& rio,
                        const StageParams& sp, const uint8_t* wam8, const float* wtab) {
@@ -873,10 +905,19 @@ struct AbsmaxArg {
     const void* base() const { return f32 ? (const void*)f32 : (const void*)u8; }
 };
 
+// The router of the same tokens, when the call is to compute it too: router matrix [E_global][H], bias or null; then
+// `ids` / `w` of moe_forward_impl are outputs.
+struct RouterArg {
+    const void* wr;
+    const void* br;
+    int E_global;
+};
+
 static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const float* w, int k, const uint8_t* w13_q,
                             AbsmaxArg a13, const uint8_t* w2_q, AbsmaxArg a2, int E_local, int e_first, int H, int FF,
                             int act_mode, int flags, const void* b13_f16, const void* b2_f16, float alpha, float limit,
-                            void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream) {
+                            void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream,
+                            RouterArg router = RouterArg{nullptr, nullptr, 0}) {
     if (T == 0) return 0;   // an empty batch has no buffers to check
     if (!x_f16 || !ids || !w || !w13_q || !a13.ok() || !w2_q || !a2.ok() || !out_f16)
         return fail(-1, "m355_moe_nf4_forward: null pointer");
@@ -919,7 +960,17 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
 
     // gate_up buckets the pairs itself when it can; the routing kernel runs when it cannot, or when gate_up is skipped
     const bool inline_route = !tiled && can_route_inline(P, E_local, H) && !(flags & M355_FLAG_SKIP_GATE_UP);
-    const RouteIO rio = {ids, P, E_local, e_first, ws.n_active, ws.offsets, ws.active, ws.sorted, ws.inv, ws.n_tiles, ws.tile_expert, ws.tile_m0};
+    // The router: inside the gate_up launch for a handful of tokens (saves a launch and its wait), else its own launch
+    const bool fuse_router = router.wr && inline_route && T <= FUSE_ROUTER_MAX_T && router.E_global <= FUSE_ROUTER_MAX_E &&
+                             !(flags & M355_FLAG_SKIP_ROUTE);
+    if (router.wr && !fuse_router && !(flags & M355_FLAG_SKIP_ROUTE)) {
+        if (int rc = m355_router_topk(x_f16, router.wr, router.br, T, H, router.E_global, k, const_cast<int32_t*>(ids),
+                                      const_cast<float*>(w), nullptr, stream))
+            return rc;
+    }
+    const RouteIO rio = {ids, P, E_local, e_first, ws.n_active, ws.offsets, ws.active, ws.sorted, ws.inv, ws.n_tiles, ws.tile_expert, ws.tile_m0,
+                         (const half_t*)x_f16, (const half_t*)router.wr, (const half_t*)router.br, H, router.E_global, k,
+                         const_cast<int32_t*>(ids), const_cast<float*>(w)};
     if (!(flags & M355_FLAG_SKIP_ROUTE) && !inline_route) {
         moe_route_kernel<<<dim3(1), dim3(ROUTE_THREADS), 0, st>>>(ids, P, E_local, e_first, ws.n_active, ws.offsets,
                                                                   ws.active, ws.sorted, ws.inv, mt_rows, ws.n_tiles,
@@ -938,12 +989,13 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
                 return rc;
     }
     if (!tiled && !(flags & M355_FLAG_SKIP_GATE_UP)) {
-        if (int rc = inline_route ? launch_gemm<0, true>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table)
-                                  : launch_gemm<0, false>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table))
+        if (int rc = fuse_router    ? launch_gemm<0, 2>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table)
+                     : inline_route ? launch_gemm<0, 1>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table)
+                                    : launch_gemm<0, 0>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table))
             return rc;
     }
     if (!tiled && !(flags & M355_FLAG_SKIP_DOWN)) {
-        if (int rc = launch_gemm<1, false>(ws.h, w2_q, w2_absmax, ws, FF, H, k, mt_rows, slots, ws.y, cus, st, rio, sp2, a2.u8, a2.table)) return rc;
+        if (int rc = launch_gemm<1, 0>(ws.h, w2_q, w2_absmax, ws, FF, H, k, mt_rows, slots, ws.y, cus, st, rio, sp2, a2.u8, a2.table)) return rc;
     }
     if (!(flags & M355_FLAG_SKIP_COMBINE)) {
         moe_combine_kernel<<<dim3(T), dim3(256), 0, st>>>(ws.y, ws.inv, w, H, k, (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0,
@@ -973,4 +1025,23 @@ extern "C" int m355_moe_nf4_forward_q8(const void* x_f16, int T, const int32_t* 
     return moe_forward_impl(x_f16, T, ids, w, k, w13_q, AbsmaxArg{nullptr, w13_absmax_u8, w13_table}, w2_q,
                             AbsmaxArg{nullptr, w2_absmax_u8, w2_table}, E_local, e_first, H, FF, act_mode, flags, b13_f16, b2_f16,
                             alpha, limit, workspace, ws_bytes, out_f16, stream);
+}
+
+extern "C" int m355_moe_nf4_forward_routed(const void* x_f16, int T, const void* wr_f16, const void* br_f16, int E_global,
+                                           int k, int32_t* ids_out, float* w_out, const uint8_t* w13_q,
+                                           const float* w13_absmax, const uint8_t* w13_absmax_u8, const float* w13_table,
+                                           const uint8_t* w2_q, const float* w2_absmax, const uint8_t* w2_absmax_u8,
+                                           const float* w2_table, int E_local, int e_first, int H, int FF, int act_mode,
+                                           int flags, const void* b13_f16, const void* b2_f16, float alpha, float limit,
+                                           void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream) {
+    if (T != 0 && (!wr_f16 || !ids_out || !w_out)) return fail(-1, "m355_moe_nf4_forward_routed: null pointer");
+    if (T != 0 && (E_global <= 0 || E_global > ROUTER_MAX_E || k > E_global || (H % 8) || !aligned(wr_f16, 16)))
+        return fail(-2, "m355_moe_nf4_forward_routed: unsupported router shape E=%d k=%d H=%d (wr 16-byte aligned, E <= %d)",
+                    E_global, k, H, ROUTER_MAX_E);
+    const bool bytes = w13_absmax == nullptr;
+    return moe_forward_impl(x_f16, T, ids_out, w_out, k, w13_q,
+                            bytes ? AbsmaxArg{nullptr, w13_absmax_u8, w13_table} : AbsmaxArg{w13_absmax, nullptr, nullptr}, w2_q,
+                            bytes ? AbsmaxArg{nullptr, w2_absmax_u8, w2_table} : AbsmaxArg{w2_absmax, nullptr, nullptr},
+                            E_local, e_first, H, FF, act_mode, flags, b13_f16, b2_f16, alpha, limit, workspace, ws_bytes,
+                            out_f16, stream, RouterArg{wr_f16, br_f16, E_global});
 }

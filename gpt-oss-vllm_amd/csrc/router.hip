@@ -2,77 +2,11 @@
 // token.  The dot products are spread over the workgroup's waves (4 experts at a time per wave so
 // each 16-byte piece of x is read once per 4 experts); wave 0 then selects the k largest logits by
 // repeated wave-wide arg-max (value descending, expert id ascending on ties).
-#include "common.h"
+#include "router_shared.h"
 
 namespace m355 {
 
 constexpr int ROUTER_THREADS = 512;
-constexpr int ROUTER_MAX_E = 1024;
-
-// Wave-wide arg-max over (v, idx): larger v wins, on equal v the smaller idx wins.
-__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(v, o, 64);
-        const int oi = __shfl_xor(idx, o, 64);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
-}
-
-// E <= 64: lane e holds logit e; its rank is the number of logits that beat it (larger, or equal with a
-// smaller index), found with E scalar broadcasts; ranks < k are the picks, in order.
-__device__ __forceinline__ void topk_softmax_wave64(float mine, int E, int k, int32_t* ids_out, float* w_out) {
-    const int lane = threadIdx.x & 63;
-    const bool valid = lane < E && !(mine != mine);
-    const float v = valid ? mine : -INFINITY;
-    int rank = 0;
-    for (int e = 0; e < E; e++) {
-        const float o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), e));
-        rank += (o > v || (o == v && e < lane)) ? 1 : 0;
-    }
-    if (lane >= E) rank = 64;
-    const unsigned long long top = __ballot(rank == 0);
-    const int l0 = top ? __builtin_ctzll(top) : 0;
-    const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l0));
-    const float p = (rank < k) ? __expf(v - mx) : 0.f;
-    const float sum = wave_sum(p);
-    if (rank < k) {
-        ids_out[rank] = lane;
-        w_out[rank] = p / sum;
-    }
-}
-
-// Selects top-k of logit[0..E) (LDS, fp32 values that are exact fp16 numbers); run by one whole wave.
-__device__ __forceinline__ void topk_softmax_wave(float* logit, int E, int k, int32_t* ids_out, float* w_out) {
-    const int lane = threadIdx.x & 63;
-    if (E <= 64) {
-        topk_softmax_wave64(lane < E ? logit[lane] : 0.f, E, k, ids_out, w_out);
-        return;
-    }
-    float myv = 0.f;
-    int myid = 0;
-    for (int j = 0; j < k; j++) {
-        float bv = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int e = lane; e < E; e += 64) {
-            const float v = logit[e];
-            if (v > bv || (v == bv && e < bi)) { bv = v; bi = e; }   // NaN logits never win
-        }
-        wave_argmax(bv, bi);
-        if (bi == 0x7fffffff) bi = j;   // all remaining are NaN / -inf: fall back to a valid id
-        if (lane == j) { myv = bv; myid = bi; }
-        if (lane == 0 && bi < E) logit[bi] = -INFINITY;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    const float mx = __shfl(myv, 0, 64);          // first pick is the largest
-    float p = (lane < k) ? __expf(myv - mx) : 0.f;
-    const float sum = wave_sum(p);
-    if (lane < k) {
-        ids_out[lane] = myid;
-        w_out[lane] = p / sum;
-    }
-}
 
 __global__ __launch_bounds__(ROUTER_THREADS) void router_topk_kernel(const half_t* __restrict__ x,
                                                                      const half_t* __restrict__ wr,
@@ -81,48 +15,8 @@ __global__ __launch_bounds__(ROUTER_THREADS) void router_topk_kernel(const half_
                                                                      half_t* __restrict__ logits_out) {
     __shared__ float logit[ROUTER_MAX_E];
     const int t = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NW = ROUTER_THREADS / 64;
-    const int chunks = H / 8;
-    const u32x4_t* xr = reinterpret_cast<const u32x4_t*>(x + (int64_t)t * H);
-    for (int e0 = wave * 4; e0 < E; e0 += NW * 4) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        // six 16-byte pieces of x and of four router rows per lane and round, all requested before any is used
-        constexpr int U = 6;
-        for (int cbase = 0; cbase < chunks; cbase += 64 * U) {
-            u32x4_t xv[U], wv[U][4];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int c = min(cbase + u * 64 + lane, chunks - 1);
-                xv[u] = xr[c];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int e = (e0 + i < E) ? e0 + i : E - 1;
-                    wv[u][i] = reinterpret_cast<const u32x4_t*>(wr + (int64_t)e * H)[c];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (cbase + u * 64 + lane < chunks) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            acc[i] = __builtin_amdgcn_fdot2(as_half2(xv[u][j]), as_half2(wv[u][i][j]), acc[i], false);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float s = wave_sum(acc[i]);
-            if (lane == 0 && e0 + i < E) {
-                const float full = s + (br ? (float)br[e0 + i] : 0.f);
-                const half_t l16 = (half_t)full;   // the reference's router output is an fp16 tensor
-                logit[e0 + i] = (float)l16;
-                if (logits_out) logits_out[(int64_t)t * E + e0 + i] = l16;
-            }
-        }
-    }
+    const int wave = threadIdx.x >> 6;
+    router_logits_wg<ROUTER_THREADS / 64>(x + (int64_t)t * H, wr, br, H, E, logit, logits_out ? logits_out + (int64_t)t * E : nullptr);
     __syncthreads();
     if (wave == 0) topk_softmax_wave(logit, E, k, ids + (int64_t)t * k, w + (int64_t)t * k);
 }

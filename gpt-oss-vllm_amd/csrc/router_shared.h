@@ -1,0 +1,124 @@
+// Device functions of the router shared by its own kernels (router.hip) and by the MoE GEMM launch that computes the
+// routing itself for a handful of tokens (moe.hip): same code, so both give the same bits.
+#pragma once
+#include "common.h"
+
+namespace m355 {
+
+constexpr int ROUTER_MAX_E = 1024;
+
+// Wave-wide arg-max over (v, idx): larger v wins, on equal v the smaller idx wins.
+__device__ __forceinline__ void wave_argmax(float& v, int& idx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o, 64);
+        const int oi = __shfl_xor(idx, o, 64);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+    }
+}
+
+// E <= 64: lane e holds logit e; its rank is the number of logits that beat it (larger, or equal with a
+// smaller index), found with E scalar broadcasts; ranks < k are the picks, in order.
+__device__ __forceinline__ void topk_softmax_wave64(float mine, int E, int k, int32_t* ids_out, float* w_out) {
+    const int lane = threadIdx.x & 63;
+    const bool valid = lane < E && !(mine != mine);
+    const float v = valid ? mine : -INFINITY;
+    int rank = 0;
+    for (int e = 0; e < E; e++) {
+        const float o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), e));
+        rank += (o > v || (o == v && e < lane)) ? 1 : 0;
+    }
+    if (lane >= E) rank = 64;
+    const unsigned long long top = __ballot(rank == 0);
+    const int l0 = top ? __builtin_ctzll(top) : 0;
+    const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l0));
+    const float p = (rank < k) ? __expf(v - mx) : 0.f;
+    const float sum = wave_sum(p);
+    if (rank < k) {
+        ids_out[rank] = lane;
+        w_out[rank] = p / sum;
+    }
+}
+
+// Selects top-k of logit[0..E) (LDS, fp32 values that are exact fp16 numbers); run by one whole wave.
+__device__ __forceinline__ void topk_softmax_wave(float* logit, int E, int k, int32_t* ids_out, float* w_out) {
+    const int lane = threadIdx.x & 63;
+    if (E <= 64) {
+        topk_softmax_wave64(lane < E ? logit[lane] : 0.f, E, k, ids_out, w_out);
+        return;
+    }
+    float myv = 0.f;
+    int myid = 0;
+    for (int j = 0; j < k; j++) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int e = lane; e < E; e += 64) {
+            const float v = logit[e];
+            if (v > bv || (v == bv && e < bi)) { bv = v; bi = e; }   // NaN logits never win
+        }
+        wave_argmax(bv, bi);
+        if (bi == 0x7fffffff) bi = j;   // all remaining are NaN / -inf: fall back to a valid id
+        if (lane == j) { myv = bv; myid = bi; }
+        if (lane == 0 && bi < E) logit[bi] = -INFINITY;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    const float mx = __shfl(myv, 0, 64);          // first pick is the largest
+    float p = (lane < k) ? __expf(myv - mx) : 0.f;
+    const float sum = wave_sum(p);
+    if (lane < k) {
+        ids_out[lane] = myid;
+        w_out[lane] = p / sum;
+    }
+}
+
+// logit_out[e] (LDS, fp32 holding exact fp16 values) = fp16(x_row . wr[e] + br[e]) for e in [0, E), computed by the
+// NW waves of the calling workgroup: a wave takes 4 experts at a time and each 16-byte piece of x once per 4 experts,
+// six pieces per lane requested before any is used.  The caller synchronises the workgroup before reading logit_out.
+template <int NW>
+__device__ __forceinline__ void router_logits_wg(const half_t* __restrict__ x_row, const half_t* __restrict__ wr,
+                                                 const half_t* __restrict__ br, int H, int E, float* logit_out,
+                                                 half_t* __restrict__ logits_global) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunks = H / 8;
+    const u32x4_t* xr = reinterpret_cast<const u32x4_t*>(x_row);
+    for (int e0 = wave * 4; e0 < E; e0 += NW * 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        constexpr int U = 6;
+        for (int cbase = 0; cbase < chunks; cbase += 64 * U) {
+            u32x4_t xv[U], wv[U][4];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int c = min(cbase + u * 64 + lane, chunks - 1);
+                xv[u] = xr[c];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int e = (e0 + i < E) ? e0 + i : E - 1;
+                    wv[u][i] = reinterpret_cast<const u32x4_t*>(wr + (int64_t)e * H)[c];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (cbase + u * 64 + lane < chunks) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            acc[i] = __builtin_amdgcn_fdot2(as_half2(xv[u][j]), as_half2(wv[u][i][j]), acc[i], false);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float s = wave_sum(acc[i]);
+            if (lane == 0 && e0 + i < E) {
+                const float full = s + (br ? (float)br[e0 + i] : 0.f);
+                const half_t l16 = (half_t)full;   // the reference's router output is an fp16 tensor
+                logit_out[e0 + i] = (float)l16;
+                if (logits_global) logits_global[e0 + i] = l16;
+            }
+        }
+    }
+}
+
+}  // namespace m355

@@ -27,6 +27,7 @@ EXPORTS = (
     "m355_paged_attn_workspace_bytes", "m355_ep_row_bytes", "m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce",
     "m355_add_rmsnorm", "m355_rope_kv_write", "m355_linear_f16", "m355_paged_attn_decode_ex",
     "m355_repack_nf4_ex", "m355_moe_nf4_forward_ex", "m355_moe_nf4_forward_q8", "m355_repack_absmax_u8",
+    "m355_moe_nf4_forward_routed",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -59,6 +60,9 @@ def load() -> ctypes.CDLL:
     L.m355_moe_nf4_forward_q8.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
                                           vp, vp, f32, f32, vp, sz, vp, vp]
     L.m355_moe_nf4_forward_q8.restype = i32
+    L.m355_moe_nf4_forward_routed.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                              i32, i32, i32, i32, i32, i32, vp, vp, f32, f32, vp, sz, vp, vp]
+    L.m355_moe_nf4_forward_routed.restype = i32
     L.m355_repack_absmax_u8.argtypes = [vp, i32, i32, i32, vp, vp]
     L.m355_repack_absmax_u8.restype = i32
     L.m355_router_topk.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
@@ -224,6 +228,44 @@ def moe_nf4_forward(x, ids, w, w13_q, w13_absmax, w2_q, w2_absmax, *, E_local: i
 
 def paged_attn_workspace_bytes(B: int, Hq: int, D: int, max_ctx: int) -> int:
     return int(load().m355_paged_attn_workspace_bytes(B, Hq, D, max_ctx))
+
+
+def moe_nf4_forward_routed(x, wr, br, k: int, w13_q, w13_absmax, w2_q, w2_absmax, *, E_local: int, e_first: int, H: int,
+                           FF: int, ids: Optional[torch.Tensor] = None, w: Optional[torch.Tensor] = None,
+                           workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                           act_mode: int = ACT_SILU_CONCAT, flags: int = FLAG_FP16_COMBINE,
+                           b13: Optional[torch.Tensor] = None, b2: Optional[torch.Tensor] = None, alpha: float = 1.702,
+                           limit: float = 7.0):
+    """Router (x @ wr.T + br -> top-k -> softmax) and the MoE layer in one call; ids [T][k] and w [T][k] receive the
+    routing (the bits router_topk gives).  Up to 8 tokens the gate_up launch computes the router itself.
+    Returns (out, ids, w).  m355_moe_nf4_forward_routed."""
+    T, E_global = x.shape[0], wr.shape[0]
+    if ids is None:
+        ids = torch.empty((T, k), dtype=torch.int32, device=x.device)
+    if w is None:
+        w = torch.empty((T, k), dtype=torch.float32, device=x.device)
+    need = moe_workspace_bytes(T, k, H, FF, E_local)
+    if workspace is None:
+        workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=x.device)
+    if out is None:
+        out = torch.empty((T, H), dtype=torch.float16, device=x.device)
+    if isinstance(w13_absmax, tuple) != isinstance(w2_absmax, tuple):
+        raise ValueError("w13_absmax and w2_absmax must both be fp32 tensors or both (codes, table) pairs")
+    if isinstance(w13_absmax, tuple):
+        (c13, t13), (c2, t2) = w13_absmax, w2_absmax
+        a13 = (None, _dev(c13, torch.uint8, "w13_absmax codes"), _dev(t13, torch.float32, "w13 table"))
+        a2 = (None, _dev(c2, torch.uint8, "w2_absmax codes"), _dev(t2, torch.float32, "w2 table"))
+    else:
+        a13 = (_dev(w13_absmax, torch.float32, "w13_absmax"), None, None)
+        a2 = (_dev(w2_absmax, torch.float32, "w2_absmax"), None, None)
+    _check(load().m355_moe_nf4_forward_routed(
+        _dev(x, torch.float16, "x"), T, _dev(wr, torch.float16, "wr"), None if br is None else _dev(br, torch.float16, "br"),
+        E_global, k, _dev(ids, torch.int32, "ids"), _dev(w, torch.float32, "w"), _dev(w13_q, torch.uint8, "w13_q"), *a13,
+        _dev(w2_q, torch.uint8, "w2_q"), *a2, E_local, e_first, H, FF, act_mode, flags,
+        None if b13 is None else _dev(b13, torch.float16, "b13"), None if b2 is None else _dev(b2, torch.float16, "b2"),
+        float(alpha), float(limit), _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
+        _dev(out, torch.float16, "out"), _stream()), "m355_moe_nf4_forward_routed")
+    return out, ids, w
 
 
 def paged_attn_decode(q, kcache, vcache, block_tables, ctx_lens, *, max_ctx: int, scale: float,

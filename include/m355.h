@@ -130,6 +130,20 @@ M355_API int m355_moe_nf4_forward_q8(const void* x_f16, int T, const int32_t* id
                                      int e_first, int H, int FF, int act_mode, int flags, const void* b13_f16,
                                      const void* b2_f16, float alpha, float limit, void* workspace, size_t ws_bytes,
                                      void* out_f16, m355_stream_t stream);
+/* Router and experts in one call: ids_out [T][k] / w_out [T][k] receive what m355_router_topk(x, wr, br) gives (same
+ * bits), then the layer runs as m355_moe_nf4_forward_ex / _q8 would (absmax: pass either the fp32 pointers or, with
+ * w13_absmax == NULL, the byte form).  Up to 8 tokens (and 256 global experts) the gate_up launch computes the router
+ * itself, every workgroup with the router kernel's own code, so a decode step of few sequences spends one launch less
+ * per layer; beyond that the router runs as its own launch.  Takes over the router nn.Linear that
+ * patches/monkey_patch_router_fp16.py:6-17 casts to fp16 and the top-k + softmax of
+ * patches/unsloth_to_vllm_converter.py:291-292, together with the forward of :282-325. */
+M355_API int m355_moe_nf4_forward_routed(const void* x_f16, int T, const void* wr_f16, const void* br_f16, int E_global,
+                                         int k, int32_t* ids_out, float* w_out, const uint8_t* w13_q,
+                                         const float* w13_absmax, const uint8_t* w13_absmax_u8, const float* w13_table,
+                                         const uint8_t* w2_q, const float* w2_absmax, const uint8_t* w2_absmax_u8,
+                                         const float* w2_table, int E_local, int e_first, int H, int FF, int act_mode,
+                                         int flags, const void* b13_f16, const void* b2_f16, float alpha, float limit,
+                                         void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream);
 /* absmax codes [rows*cols/64] bytes, checkpoint order -> the tile order of absmax_tiled in m355_repack_nf4. */
 M355_API int m355_repack_absmax_u8(const uint8_t* absmax_u8, int rows, int cols, int row_order, uint8_t* absmax_tiled,
                                    m355_stream_t stream);

@@ -500,3 +500,33 @@ def test_moe_tile_kernel_prefill_size(ref, m355, cuda):
     ids_s = np.vectorize(remap.get)(ids_h[sample]).astype(np.int32)
     want = ref.moe_forward(x[sample].cpu().numpy(), ids_s, w_h[sample], **sub, E_local=len(used), H=H, FF=FF, flags=0)
     _close(out[sample].cpu().numpy(), want)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("T,E,k,bias,H,FF", [(1, 32, 4, False, 2880, 2880), (3, 32, 4, True, 2880, 2880),
+                                             (8, 128, 4, False, 256, 192), (9, 32, 4, True, 256, 192),
+                                             (2, 256, 5, True, 256, 192), (40, 8, 2, False, 256, 192)])
+def test_router_and_experts_in_one_call(T, E, k, bias, H, FF, ref, m355, cuda):
+    """m355_moe_nf4_forward_routed against router_topk followed by the forward: identical ids, weights and output
+    (up to 8 tokens the gate_up launch computes the router itself with the router kernel's code; beyond, the call
+    launches the router kernel)."""
+    sd = ref.stream_seed(T, E, k, 808)
+    layer = ref.synth_layer(sd, E, H, FF)
+    tl = tiled_layer(m355, layer, E, H, FF, cuda)
+    x = _to_dev(ref.normal_f16(ref.stream_seed(sd, 1), (T, H)), cuda)
+    wr = _to_dev(ref.normal_f16(ref.stream_seed(sd, 2), (E, H), 0.05), cuda)
+    br = _to_dev(ref.normal_f16(ref.stream_seed(sd, 3), (E,), 0.1), cuda) if bias else None
+    ids0, w0 = m355.router_topk(x, wr, br, k)
+    want = m355.moe_nf4_forward(x, ids0, w0, *tl, E_local=E, e_first=0, H=H, FF=FF)
+    out, ids, w = m355.moe_nf4_forward_routed(x, wr, br, k, *tl, E_local=E, e_first=0, H=H, FF=FF)
+    torch.cuda.synchronize()
+    assert torch.equal(ids, ids0) and torch.equal(w, w0)
+    assert torch.equal(out, want)
+    # a shard (local experts 2..) sees the same routing and adds up with the rest as the separate calls do
+    if E >= 8:
+        sl = slice(2, E)
+        shard = tuple(t[sl].contiguous() for t in tl)
+        o_sh, ids_sh, _ = m355.moe_nf4_forward_routed(x, wr, br, k, *shard, E_local=E - 2, e_first=2, H=H, FF=FF)
+        want_sh = m355.moe_nf4_forward(x, ids0, w0, *shard, E_local=E - 2, e_first=2, H=H, FF=FF)
+        torch.cuda.synchronize()
+        assert torch.equal(ids_sh, ids0) and torch.equal(o_sh, want_sh)
