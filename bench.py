@@ -103,8 +103,14 @@ class DecodeStep:
         for lay in self.L:
             lib.paged_attn_decode(lay["q"], lay["kc"], lay["vc"], self.block_tables, self.ctx_lens, max_ctx=self.ctx,
                                   scale=D ** -0.5, out=lay["attn_out"])
-            lib.router_topk(lay["x"], lay["wr"], None, TOPK, ids=lay["ids"], w=lay["w"])
-            lay["ep"].forward(lay["x"], lay["ids"], lay["w"], out=lay["out"])
+            ep = lay["ep"]
+            if ep.world == 1 and not ep.force_exchange:
+                # router and experts in one library call (up to 8 tokens gate_up computes the router itself)
+                lib.moe_nf4_forward_routed(lay["x"], lay["wr"], None, TOPK, *ep.weights, E_local=ep.epr, e_first=0, H=H, FF=FF,
+                                           ids=lay["ids"], w=lay["w"], workspace=ep.workspace, out=lay["out"], flags=ep.flags)
+            else:
+                lib.router_topk(lay["x"], lay["wr"], None, TOPK, ids=lay["ids"], w=lay["w"])
+                ep.forward(lay["x"], lay["ids"], lay["w"], out=lay["out"])
 
     def capture(self):
         s = torch.cuda.Stream()

@@ -136,8 +136,8 @@ class GptOssDecodeLayer:
                               workspace=self.attn_ws, out=self.attn, sinks=w.get("sinks"), window=self.window)
         lib.linear_f16(self.attn.view(T, self.Hq * self.D), w["wo"], w.get("bo"), resid=self.resid, out=self.resid2)
         lib.add_rmsnorm(self.resid2, None, w["ln2"], self.eps, out=self.h2)
-        lib.router_topk(self.h2, w["router_w"], w.get("router_b"), self.k, ids=self.ids, w=self.wts)
-        lib.moe_nf4_forward(self.h2, self.ids, self.wts, w["w13_q"], w["w13_absmax"], w["w2_q"], w["w2_absmax"],
-                            E_local=self.E, e_first=0, H=self.H, FF=self.FF, workspace=self.moe_ws, out=self.moe_out,
-                            act_mode=self.act_mode, flags=0, b13=w.get("b13"), b2=w.get("b2"))
+        lib.moe_nf4_forward_routed(self.h2, w["router_w"], w.get("router_b"), self.k, w["w13_q"], w["w13_absmax"], w["w2_q"],
+                                   w["w2_absmax"], E_local=self.E, e_first=0, H=self.H, FF=self.FF, ids=self.ids, w=self.wts,
+                                   workspace=self.moe_ws, out=self.moe_out, act_mode=self.act_mode, flags=0,
+                                   b13=w.get("b13"), b2=w.get("b2"))
         return self.resid2, self.moe_out
