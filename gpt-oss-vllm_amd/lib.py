@@ -27,7 +27,7 @@ EXPORTS = (
     "m355_paged_attn_workspace_bytes", "m355_ep_row_bytes", "m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce",
     "m355_add_rmsnorm", "m355_rope_kv_write", "m355_linear_f16", "m355_paged_attn_decode_ex",
     "m355_repack_nf4_ex", "m355_moe_nf4_forward_ex", "m355_moe_nf4_forward_q8", "m355_repack_absmax_u8",
-    "m355_moe_nf4_forward_routed",
+    "m355_moe_nf4_forward_routed", "m355_attn_prefill",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -63,6 +63,9 @@ def load() -> ctypes.CDLL:
     L.m355_moe_nf4_forward_routed.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                               i32, i32, i32, i32, i32, i32, vp, vp, f32, f32, vp, sz, vp, vp]
     L.m355_moe_nf4_forward_routed.restype = i32
+    L.m355_attn_prefill.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                    f32, vp, i32, vp, vp]
+    L.m355_attn_prefill.restype = i32
     L.m355_repack_absmax_u8.argtypes = [vp, i32, i32, i32, vp, vp]
     L.m355_repack_absmax_u8.restype = i32
     L.m355_router_topk.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp]
@@ -384,4 +387,25 @@ def repack_absmax_u8(codes: torch.Tensor, rows: int, cols: int, row_order: int =
     out = torch.empty_like(codes)
     _check(load().m355_repack_absmax_u8(_dev(codes, torch.uint8, "codes"), rows, cols, int(row_order),
                                         _dev(out, torch.uint8, "out"), _stream()), "m355_repack_absmax_u8")
+    return out
+
+
+def attn_prefill(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, seq_starts: torch.Tensor, max_seq: int, *, scale: float,
+                 sinks: Optional[torch.Tensor] = None, window: int = 0, out: Optional[torch.Tensor] = None):
+    """Causal self-attention of packed prompts: q [tokens][Hq][64], k / v [tokens][Hkv][64] fp16 (the token dimension may
+    be strided, e.g. slices of a fused qkv tensor), seq_starts int32 [B + 1] on the GPU.  m355_attn_prefill."""
+    T, Hq, D = q.shape
+    Hkv = k.shape[1]
+    for name, t in (("q", q), ("k", k), ("v", v)):
+        if not t.is_cuda or t.dtype != torch.float16 or t.stride(2) != 1 or t.stride(1) != D:
+            raise Mi355LibraryError(f"{name} must be a GPU fp16 tensor [tokens][heads][{D}] with contiguous heads")
+    if k.stride(0) != v.stride(0):
+        raise ValueError("k and v must share their token stride")
+    if out is None:
+        out = torch.empty((T, Hq, D), dtype=torch.float16, device=q.device)
+    B = seq_starts.numel() - 1
+    _check(load().m355_attn_prefill(q.data_ptr(), k.data_ptr(), v.data_ptr(), _dev(seq_starts, torch.int32, "seq_starts"), B,
+                                    int(max_seq), Hq, Hkv, D, q.stride(0), k.stride(0), out.stride(0), float(scale),
+                                    None if sinks is None else _dev(sinks, torch.float16, "sinks"), int(window),
+                                    _dev(out, torch.float16, "out"), _stream()), "m355_attn_prefill")
     return out

@@ -144,6 +144,18 @@ M355_API int m355_moe_nf4_forward_routed(const void* x_f16, int T, const void* w
                                          const float* w2_table, int E_local, int e_first, int H, int FF, int act_mode,
                                          int flags, const void* b13_f16, const void* b2_f16, float alpha, float limit,
                                          void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream);
+/*
+ * Causal self-attention over whole prompts (prefill), the companion of m355_paged_attn_decode for the tokens that
+ * arrive together: q [tokens][Hq][D], k / v [tokens][Hkv][D] fp16 with token strides in elements (so slices of a fused
+ * qkv tensor can be passed), sequences packed one after the other, seq_starts [B + 1] (device) their first tokens;
+ * query i of a sequence sees keys 0..i of the same sequence (window > 0: the last `window` of them; sinks [Hq] fp16 or
+ * NULL: one more logit per head in the denominator).  max_seq = the longest sequence (host).  D == 64, Hq == 8 Hkv.
+ * Takes over the flash-attn 2 varlen call the reference reaches through vLLM's FA2 backend for prompts
+ * (patches/patch_1..3, VLLM_FLASH_ATTN_VERSION=2 in patches/gpt_oss_server.py:26).
+ */
+M355_API int m355_attn_prefill(const void* q_f16, const void* k_f16, const void* v_f16, const int32_t* seq_starts, int B,
+                               int max_seq, int Hq, int Hkv, int D, int64_t q_stride, int64_t kv_stride, int64_t o_stride,
+                               float scale, const void* sinks_f16, int window, void* out_f16, m355_stream_t stream);
 /* absmax codes [rows*cols/64] bytes, checkpoint order -> the tile order of absmax_tiled in m355_repack_nf4. */
 M355_API int m355_repack_absmax_u8(const uint8_t* absmax_u8, int rows, int cols, int row_order, uint8_t* absmax_tiled,
                                    m355_stream_t stream);

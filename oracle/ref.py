@@ -188,6 +188,35 @@ def paged_attn_decode_ex(q, kcache, vcache, block_tables, ctx_lens, scale: float
 # ---------------------------------------------------------------------------------------------
 # numpy twin of the dequantizer (cross-checks the C code; same reference lines)
 # ---------------------------------------------------------------------------------------------
+def attn_prefill(q, k, v, seq_starts, scale: float, sinks=None, window: int = 0) -> np.ndarray:
+    """Causal self-attention of packed prompts in fp32 numpy (what flash-attn's varlen call computes; the reference
+    holds no fixture for it): q [tokens][Hq][D], k / v [tokens][Hkv][D]; query i of a sequence sees keys 0..i of it
+    (the last `window` of them when window > 0); a sink adds exp(sink) to the denominator."""
+    q32, k32, v32 = (np.asarray(a, dtype=np.float16).astype(np.float32) for a in (q, k, v))
+    T, Hq, D = q32.shape
+    G = Hq // k32.shape[1]
+    out = np.zeros((T, Hq, D), np.float32)
+    for b in range(len(seq_starts) - 1):
+        s0, s1 = int(seq_starts[b]), int(seq_starts[b + 1])
+        L = s1 - s0
+        if L <= 0:
+            continue
+        i, j = np.arange(L)[:, None], np.arange(L)[None, :]
+        ok = (j <= i) & ((j > i - window) if window > 0 else True)
+        for h in range(Hq):
+            sc = (q32[s0:s1, h] @ k32[s0:s1, h // G].T) * scale
+            sc = np.where(ok, sc, -np.inf)
+            m = sc.max(axis=1, keepdims=True)
+            if sinks is not None:
+                m = np.maximum(m, np.float32(sinks[h]))
+            p = np.exp(sc - m)
+            den = p.sum(axis=1, keepdims=True)
+            if sinks is not None:
+                den = den + np.exp(np.float32(sinks[h]) - m)
+            out[s0:s1, h] = (p @ v32[s0:s1, h // G]) / den
+    return out.astype(np.float16)
+
+
 def nf4_dequant_numpy(q, n_params: int, absmax_f32) -> np.ndarray:
     q = np.asarray(q, dtype=np.uint8).reshape(-1)
     a = np.asarray(absmax_f32, dtype=np.float32).reshape(-1)

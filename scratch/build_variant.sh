@@ -4,7 +4,7 @@ set -e
 name=$1; shift
 root=$(cd $(dirname $0)/.. && pwd)
 out=$root/scratch/exp; mkdir -p $out/obj_$name
-for f in api dequant router moe moe_tile attn ep layer dense; do
+for f in api dequant router moe moe_tile attn attn_prefill ep layer dense; do
   src=$root/gpt-oss-vllm_amd/csrc/$f.hip
   obj=$root/gpt-oss-vllm_amd/csrc/build/$f.o
   if [ "$f" = "moe_tile" ] || [ "$f" = "moe" ]; then

@@ -530,3 +530,51 @@ def test_router_and_experts_in_one_call(T, E, k, bias, H, FF, ref, m355, cuda):
         want_sh = m355.moe_nf4_forward(x, ids0, w0, *shard, E_local=E - 2, e_first=2, H=H, FF=FF)
         torch.cuda.synchronize()
         assert torch.equal(ids_sh, ids0) and torch.equal(o_sh, want_sh)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("lens,window,use_sinks", [([1], 0, False), ([37], 0, False), ([200, 3, 65], 0, True),
+                                                   ([130, 64], 48, True), ([300], 128, False), ([0, 5, 33], 0, False)])
+def test_attention_prefill_vs_oracle(lens, window, use_sinks, ref, m355, cuda):
+    """Prompt attention lives in flash-attn in the reference (no fixture): parity unpinned, checked against the
+    oracle's fp32 causal attention.  q, k, v are slices of one fused [tokens][(Hq + 2 Hkv) D] tensor, as a model's qkv
+    projection leaves them.  Tolerance 2e-3 * max|out| + 1e-5 (probabilities are rounded to fp16 for the second product)."""
+    Hq, Hkv, D = 64, 8, 64
+    T = sum(lens)
+    sd = ref.stream_seed(*lens, window, 31)
+    qkv = ref.normal_f16(ref.stream_seed(sd, 1), (max(T, 1), (Hq + 2 * Hkv) * D))[:T]
+    sinks = ref.normal_f16(ref.stream_seed(sd, 2), (Hq,), 1.0) if use_sinks else None
+    starts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    qkv_d = _to_dev(qkv, cuda) if T else torch.empty((0, (Hq + 2 * Hkv) * D), dtype=torch.float16, device=cuda)
+    q = qkv_d[:, :Hq * D].view(T, Hq, D)
+    k = qkv_d[:, Hq * D:(Hq + Hkv) * D].view(T, Hkv, D)
+    v = qkv_d[:, (Hq + Hkv) * D:].view(T, Hkv, D)
+    scale = D ** -0.5
+    out = m355.attn_prefill(q, k, v, _to_dev(starts, cuda), max(lens), scale=scale,
+                            sinks=None if sinks is None else _to_dev(sinks, cuda), window=window)
+    torch.cuda.synchronize()
+    qn = qkv[:, :Hq * D].reshape(T, Hq, D)
+    kn = qkv[:, Hq * D:(Hq + Hkv) * D].reshape(T, Hkv, D)
+    vn = qkv[:, (Hq + Hkv) * D:].reshape(T, Hkv, D)
+    want = ref.attn_prefill(qn, kn, vn, starts, scale, sinks, window)
+    _close(out.cpu().numpy(), want)
+
+
+def test_attention_prefill_last_token_equals_decode(ref, m355, cuda):
+    """The last query of a prompt through the prefill kernel = the decode kernel's answer for the same cache."""
+    Hq, Hkv, D, bs, L = 64, 8, 64, 16, 150
+    sd = ref.stream_seed(77, 150)
+    q = ref.normal_f16(ref.stream_seed(sd, 1), (L, Hq, D))
+    k = ref.normal_f16(ref.stream_seed(sd, 2), (L, Hkv, D))
+    v = ref.normal_f16(ref.stream_seed(sd, 3), (L, Hkv, D))
+    nblk = (L + bs - 1) // bs
+    kc = np.zeros((nblk, bs, Hkv, D), np.float16)
+    vc = np.zeros((nblk, bs, Hkv, D), np.float16)
+    kc.reshape(-1, Hkv, D)[:L], vc.reshape(-1, Hkv, D)[:L] = k, v
+    starts = _to_dev(np.array([0, L], np.int32), cuda)
+    pre = m355.attn_prefill(_to_dev(q, cuda), _to_dev(k, cuda), _to_dev(v, cuda), starts, L, scale=D ** -0.5)
+    dec = m355.paged_attn_decode(_to_dev(q[L - 1:L], cuda), _to_dev(kc, cuda), _to_dev(vc, cuda),
+                                 _to_dev(np.arange(nblk, dtype=np.int32).reshape(1, nblk), cuda),
+                                 _to_dev(np.array([L], np.int32), cuda), max_ctx=L, scale=D ** -0.5)
+    torch.cuda.synchronize()
+    _close(pre[L - 1].cpu().numpy(), dec[0].cpu().numpy())
