@@ -37,7 +37,8 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
     const int32_t* __restrict__ seq_starts, int Hq, int64_t q_stride, int64_t kv_stride, int64_t o_stride, float scale,
     const half_t* __restrict__ sinks, int window, half_t* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.z, hk = blockIdx.y, q0 = blockIdx.x * AP_QBLK;
+    // late query blocks see the most keys: they go first, so the launch does not end on its longest workgroups
+    const int b = blockIdx.z, hk = blockIdx.y, q0 = (gridDim.x - 1 - blockIdx.x) * AP_QBLK;
     const int s0 = seq_starts[b];
     const int L = seq_starts[b + 1] - s0;
     if (q0 >= L) return;
@@ -81,7 +82,8 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
     const int dg = (lane >> 4) & 1, ga = (lane & 15) >> 2, gc = lane & 3;
     const uint32_t voff = AP_TILE_BYTES + (4 * hh + ga) * 128 + (16 * dg + 4 * gc) * 2;
 
-    float m_run = -INFINITY, l_run = 0.f;
+    const float scale2 = scale * 1.44269504088896341f;
+    float m_run = -INFINITY, l_run = 0.f;   // running maximum (log2 units) and denominator of this lane's query
     float16_t o[2];
 #pragma unroll
     for (int i = 0; i < 16; i++) { o[0][i] = 0.f; o[1][i] = 0.f; }
@@ -110,18 +112,18 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
             for (int i = 0; i < 16; i++) {
                 const int kabs = kbase + (i & 3) + 8 * (i >> 2) + 4 * hh;
                 const bool ok = kabs <= qabs && (window <= 0 || kabs > qabs - window);
-                x[i] = ok ? x[i] * scale : -INFINITY;
+                x[i] = ok ? x[i] * scale2 : -INFINITY;   // scores in units of log2(e): exp2 below
                 mx = fmaxf(mx, x[i]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;   // every key so far masked: all terms are 0
-            const float alpha = __expf(m_run - m_use);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
             float rs = 0.f;
             half8_t pf[2];
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const float p = __expf(x[i] - m_use);
+                const float p = __builtin_amdgcn_exp2f(x[i] - m_use);
                 rs += p;
                 pf[i >> 3][i & 7] = (half_t)p;
             }
@@ -145,10 +147,10 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
         }
     }
     if (sinks) {   // a sink is one more logit in the softmax denominator (its value row is dropped)
-        const float sk = (float)sinks[hq];
+        const float sk = (float)sinks[hq] * 1.44269504088896341f;
         const float m2 = fmaxf(m_run, sk);
-        const float f = __expf(m_run - m2);
-        l_run = l_run * f + __expf(sk - m2);
+        const float f = __builtin_amdgcn_exp2f(m_run - m2);
+        l_run = l_run * f + __builtin_amdgcn_exp2f(sk - m2);
 #pragma unroll
         for (int i = 0; i < 16; i++) { o[0][i] *= f; o[1][i] *= f; }
     }
