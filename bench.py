@@ -302,7 +302,7 @@ def full_layer_leg(lib, main_step, batch, ctx, layers, device, steps, warmup):
 def prefill_leg(lib, main_step, device, tokens, reps=3):
     """The same experts fed a prefill-sized batch (configs[4] of BASELINE.json is an 8k-token prefill): per layer router top-k
     + fused NF4 MoE, where the library picks its kernel for many tokens per expert (256-token tiles, weights
-    dequantised once per tile, MFMA-bound).  Attention prefill is not part of the path built here.  The MFMA figure
+    dequantised once per tile, MFMA-bound), preceded by the prompt attention of the same tokens.  The MFMA figure
     times the gate_up launches alone (one HIP graph of all layers, HIP events on the launch stream)."""
     g = torch.Generator(device=device)
     g.manual_seed(8192)
@@ -314,8 +314,18 @@ def prefill_leg(lib, main_step, device, tokens, reps=3):
     ws = torch.empty(lib.moe_workspace_bytes(T, TOPK, H, FF, E), dtype=torch.uint8, device=device)
     F = lib.FLAG_FP16_COMBINE
 
-    def run(flags, route=True):
-        for lay in main_step.L:
+    # prompt attention of the same tokens: one packed sequence, gpt-oss's alternation of 128-token sliding-window and
+    # full-attention layers, q / k / v as slices of one fused projection output (shared by the layers: synthetic)
+    qkv = torch.randn((T, (HQ + 2 * HKV) * D), device=device, generator=g).half()
+    q_, k_, v_ = (qkv[:, :HQ * D].view(T, HQ, D), qkv[:, HQ * D:(HQ + HKV) * D].view(T, HKV, D),
+                  qkv[:, (HQ + HKV) * D:].view(T, HKV, D))
+    attn_out = torch.empty((T, HQ, D), dtype=torch.float16, device=device)
+    starts = torch.tensor([0, T], dtype=torch.int32, device=device)
+
+    def run(flags, route=True, attention=False):
+        for li, lay in enumerate(main_step.L):
+            if attention:
+                lib.attn_prefill(q_, k_, v_, starts, T, scale=D ** -0.5, window=128 if li % 2 == 0 else 0, out=attn_out)
             if route:
                 lib.router_topk(x, lay["wr"], None, TOPK, ids=ids, w=w)
             lib.moe_nf4_forward(x, ids, w, lay["w13_q"], lay["w13_a"], lay["w2_q"], lay["w2_a"], E_local=E, e_first=0,
@@ -343,7 +353,8 @@ def prefill_leg(lib, main_step, device, tokens, reps=3):
         b.synchronize()
         return a.elapsed_time(b) * 1e-3 / reps
 
-    t_all = graph_time(lambda: run(F))
+    t_all = graph_time(lambda: run(F, attention=True))
+    t_moe = graph_time(lambda: run(F))
     only_gate_up = F | lib.FLAG_SKIP_ROUTE | lib.FLAG_SKIP_DOWN | lib.FLAG_SKIP_COMBINE
     only_down = F | lib.FLAG_SKIP_ROUTE | lib.FLAG_SKIP_GATE_UP | lib.FLAG_SKIP_COMBINE
     t_gu = graph_time(lambda: run(only_gate_up, route=False)) / len(main_step.L)
@@ -351,8 +362,10 @@ def prefill_leg(lib, main_step, device, tokens, reps=3):
     fl_gu = float(T) * TOPK * GATE_UP_FLOPS_PER_PAIR
     return {
         "value": T / t_all, "unit": "tokens/s", "tokens": T, "ms_per_layer": t_all / len(main_step.L) * 1e3,
-        "what": f"{T}-token prefill through router top-k + fused NF4 MoE of {len(main_step.L)} layers ({E} experts, top-4: "
-                f"about {T * TOPK // E} tokens per expert), one HIP graph; attention prefill not included",
+        "ms_per_layer_router_and_moe": t_moe / len(main_step.L) * 1e3,
+        "what": f"{T}-token prompt (one sequence) through prompt attention (sliding window 128 on even layers, full on odd), "
+                f"router top-k and fused NF4 MoE of {len(main_step.L)} layers ({E} experts, top-4: about {T * TOPK // E} "
+                f"tokens per expert), one HIP graph",
         "roofline": {"bound": "mfma", "kernel": "moe_tile_gemm_kernel<gate_up> (NF4 dequant fused into the grouped GEMM, 256-token tiles)",
                      "achieved": fl_gu / t_gu / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": fl_gu / t_gu / 1e12 / MFMA_PEAK_TFLOPS, "avg_us": t_gu * 1e6, "flops_per_launch": fl_gu,
