@@ -61,7 +61,8 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
     const int t_lo = k_lo / AP_KVBLK, t_hi = (k_hi + AP_KVBLK - 1) / AP_KVBLK;
 
     // staging: one DMA instruction per wave and tile for K and one for V, 8 keys x 128 bytes each.  K chunks are
-    // XOR-swizzled on the source side (conflict-free ds_read_b128 of the A fragments); V rows stay plain.
+    // XOR-swizzled on the source side (conflict-free ds_read_b128 of the A fragments); V rows 2, 3 (mod 4) have their
+    // 64-byte halves swapped, so the 4 rows x 64 bytes that a 32-lane half reads transposed cover every bank once.
     const int skey = 8 * wave + (lane >> 3);   // key of the tile this lane stages
     const int kchunk = (lane & 7) ^ ((skey >> 1) & 7);
     auto stage = [&](int t, int buf) {
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
         const half_t* vrow = v + (int64_t)(s0 + key) * kv_stride + (int64_t)hk * AP_D;
         __builtin_amdgcn_global_load_lds((ap_glb_void_t*)(krow + 8 * kchunk),
                                          (ap_lds_void_t*)(smem + buf * 2 * AP_TILE_BYTES + wave * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((ap_glb_void_t*)(vrow + 8 * (lane & 7)),
+        __builtin_amdgcn_global_load_lds((ap_glb_void_t*)(vrow + 8 * ((lane & 7) ^ (((skey >> 1) & 1) << 2))),
                                          (ap_lds_void_t*)(smem + buf * 2 * AP_TILE_BYTES + AP_TILE_BYTES + wave * 1024), 16, 0, 0);
     };
     // A fragment of S^T step s: K[key qi of the half tile][16 s + 8 h ..] = chunk 2 s + h of the key's line
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
     // 4 keys x 16 columns and lane i receives column i of the 4 keys.  Group (h, dg): keys 4 h + .., columns 16 dg + ..
     const int dg = (lane >> 4) & 1, ga = (lane & 15) >> 2, gc = lane & 3;
     const uint32_t voff = AP_TILE_BYTES + (4 * hh + ga) * 128 + (16 * dg + 4 * gc) * 2;
+    const uint32_t vswz = (uint32_t)(((ga >> 1) & 1) * 64);   // which 64-byte half holds columns 0..31 of this lane's row
 
     const float scale2 = scale * 1.44269504088896341f;
     float m_run = -INFINITY, l_run = 0.f;   // running maximum (log2 units) and denominator of this lane's query
@@ -108,12 +110,22 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
             }
             // register i of lane (q, h) is key kbase + (i & 3) + 8 (i >> 2) + 4 h
             float mx = -INFINITY;
+            // only half tiles on the diagonal or on the window's edge need the per-element test
+            const bool edge = kbase + 31 > q0 || (window > 0 && kbase <= q0 + AP_QBLK - 1 - window);
+            if (edge) {
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int kabs = kbase + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                const bool ok = kabs <= qabs && (window <= 0 || kabs > qabs - window);
-                x[i] = ok ? x[i] * scale2 : -INFINITY;   // scores in units of log2(e): exp2 below
-                mx = fmaxf(mx, x[i]);
+                for (int i = 0; i < 16; i++) {
+                    const int kabs = kbase + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                    const bool ok = kabs <= qabs && (window <= 0 || kabs > qabs - window);
+                    x[i] = ok ? x[i] * scale2 : -INFINITY;   // scores in units of log2(e): exp2 below
+                    mx = fmaxf(mx, x[i]);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    x[i] *= scale2;
+                    mx = fmaxf(mx, x[i]);
+                }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m_run, mx);
@@ -130,14 +142,16 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
             rs += __shfl_xor(rs, 32, 64);
             l_run = l_run * alpha + rs;
             m_run = m_new;
+            if (__any(alpha != 1.0f)) {   // (once the running maxima have settled nothing is rescaled)
 #pragma unroll
-            for (int i = 0; i < 16; i++) { o[0][i] *= alpha; o[1][i] *= alpha; }
+                for (int i = 0; i < 16; i++) { o[0][i] *= alpha; o[1][i] *= alpha; }
+            }
             // O^T[d][q] += V^T[d][key] P^T[key][q]: element j of step s2 is key 16 s2 + 8 (j >> 2) + 4 h + (j & 3)
 #pragma unroll
             for (int dt = 0; dt < 2; dt++)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; s2++) {
-                    const uint32_t va = base + voff + (uint32_t)((sub * 32 + 16 * s2) * 128 + dt * 64);
+                    const uint32_t va = base + voff + (uint32_t)((sub * 32 + 16 * s2) * 128) + ((uint32_t)(dt * 64) ^ vswz);
                     const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<ap_lds_s4_t*>(va));
                     const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<ap_lds_s4_t*>(va + 8 * 128));
                     typedef short short8_t __attribute__((ext_vector_type(8)));
