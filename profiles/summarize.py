@@ -31,7 +31,9 @@ for leg, tr_file in traces:
           if short.startswith(a):
               short = b
       short = short.replace("_ZN4m35516moe_route_kernelE", "moe_route").replace("_ZN4m35523router_topk_tile_kernelE", "router_topk_tile")
-      short = short.replace("m355::moe_route_kernel", "moe_route")
+      short = short.replace("m355::moe_route_kernel", "moe_route").replace("m355::attn_prefill_kernel", "attn_prefill").replace("_ZN4m35519attn_prefill_kernelE", "attn_prefill")
+      if short.startswith("_ZN4m35523router_topk_tile_kernel"):
+          short = "router_topk_tile"
       short = short.replace("_ZN4m35524paged_attn_decode_kernelE", "paged_attn_decode").replace("_ZN4m35518router_topk_kernelE", "router_topk")
       short = short.replace("_ZN4m35518moe_combine_kernelE", "moe_combine").split("PK")[0].split("EPK")[0]
       key = (leg, short, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Workgroup_Size_X"]), int(r["LDS_Block_Size"]),
@@ -54,8 +56,8 @@ bench = json.load(open(f"{src}/bench_line.json"))
 with open(f"profiles/{tag}_summary.md", "w") as out:
     out.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bs1 [--batch-per-gpu 1]`\n\n")
     out.write("Two runs: the default workload (bs=32 per GPU) and `--batch-per-gpu 1`; both with `--no-bs1` so a row is one configuration. "
-              "Each run ends with the 8192-token prefill leg: its launches are the rows with 8192 workgroups (router, combine), "
-              "moe_route and moe_tile_gemm.\n\n")
+              "Each run ends with the 8192-token prefill leg: its launches are attn_prefill, router_topk_tile, moe_route, "
+              "moe_tile_gemm and the moe_combine rows with 8192 workgroups.\n\n")
     out.write("| leg | kernel | workgroups | threads | launches | avg us | min us | max us |\n|---|---|---|---|---|---|---|---|\n")
     for k, v in sorted(groups.items()):
         out.write(f"| {k[0]} | {k[1]} | {k[2]} | {k[3]} | {len(v)} | {sum(v) / len(v) / 1e3:.2f} | {min(v) / 1e3:.2f} | {max(v) / 1e3:.2f} |\n")
