@@ -118,6 +118,32 @@ class GptOssDecodeLayer:
         qkv = lib.linear_f16(h, w["wqkv"], w.get("bqkv"))
         lib.rope_kv_write(qkv, cos, sin, positions, slots, kcache, vcache, Hq=self.Hq, Hkv=self.Hkv, D=self.D)
 
+    def prefill(self, resid_in, delta, positions, slots, seq_starts, max_seq: int, kcache, vcache, cos, sin):
+        """The same layer over whole prompts: resid_in [tokens][H] holds the sequences one after another, seq_starts
+        int32 [B + 1] their first rows, positions the rotary positions, slots the cache rows of the tokens (negative:
+        not cached).  Attention is causal within each sequence (m355_attn_prefill) over the rotated keys of this
+        call, so the sequences must start at position 0 of their context.  Buffers are allocated per call (prompt
+        sizes vary).  Returns (residual stream after attention, expert output), as forward does."""
+        lib, w = self.lib, self.w
+        T, dev = resid_in.shape[0], resid_in.device
+        resid = torch.empty_like(resid_in)
+        h1 = lib.add_rmsnorm(resid_in, delta, w["ln1"], self.eps, resid_out=resid)
+        qkv = lib.linear_f16(h1, w["wqkv"], w.get("bqkv"))
+        # rotated keys and the values of the prompt, token-major, for the attention; then the same rows into the cache
+        k_rows = torch.empty((T, 1, self.Hkv, self.D), dtype=torch.float16, device=dev)
+        v_rows = torch.empty_like(k_rows)
+        q = lib.rope_kv_write(qkv, cos, sin, positions, torch.arange(T, dtype=torch.int64, device=dev), k_rows, v_rows,
+                              Hq=self.Hq, Hkv=self.Hkv, D=self.D)
+        lib.rope_kv_write(qkv, cos, sin, positions, slots, kcache, vcache, Hq=self.Hq, Hkv=self.Hkv, D=self.D, q_out=q)
+        attn = lib.attn_prefill(q, k_rows.view(T, self.Hkv, self.D), v_rows.view(T, self.Hkv, self.D), seq_starts, max_seq,
+                                scale=self.D ** -0.5, sinks=w.get("sinks"), window=self.window)
+        resid2 = lib.linear_f16(attn.view(T, self.Hq * self.D), w["wo"], w.get("bo"), resid=resid)
+        h2 = lib.add_rmsnorm(resid2, None, w["ln2"], self.eps)
+        moe_out, _, _ = lib.moe_nf4_forward_routed(h2, w["router_w"], w.get("router_b"), self.k, w["w13_q"], w["w13_absmax"],
+                                                   w["w2_q"], w["w2_absmax"], E_local=self.E, e_first=0, H=self.H, FF=self.FF,
+                                                   act_mode=self.act_mode, flags=0, b13=w.get("b13"), b2=w.get("b2"))
+        return resid2, moe_out
+
     def forward(self, resid_in, delta, positions, slots, block_tables, ctx_lens, kcache, vcache, cos, sin, max_ctx: int):
         """resid_in [T][H]: the residual stream entering the layer, delta: the previous layer's expert output still to
         be added (None for the first layer).  ctx_lens counts the new token.  Returns (residual stream after

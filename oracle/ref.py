@@ -505,6 +505,16 @@ def golden_forward_case(name: str) -> dict:
     return dict(H=H, FF=FF, E=E, k=k, T=T, x=x, logits=logits, **layer)
 
 
+def prompt_attention_case(name):
+    """Seeded q, k, v, sinks of the prompt-attention cases ("prompt_full", "prompt_window": 100 tokens, 8 query heads on
+    1 KV head, window 0 / 24): what tests/golden/make_layer_golden.py fed to transformers' eager_attention_forward."""
+    S, Hq_, Hkv_, D_ = 100, 8, 1, 64
+    sd = stream_seed(740, 0 if name == "prompt_full" else 1)
+    return dict(S=S, Hq=Hq_, Hkv=Hkv_, D=D_, window=0 if name == "prompt_full" else 24,
+                q=normal_f16(stream_seed(sd, 1), (S, Hq_, D_)), k=normal_f16(stream_seed(sd, 2), (S, Hkv_, D_)),
+                v=normal_f16(stream_seed(sd, 3), (S, Hkv_, D_)), sinks=normal_f16(stream_seed(sd, 4), (Hq_,), 2.0))
+
+
 def decoder_layer_case(name):
     """Seeded parameters and inputs of the whole-decoder-layer cases ("sliding", "full"): what
     tests/golden/make_layer_golden.py fed to transformers' GptOssDecoderLayer and what the GPU tests feed to the kernels."""

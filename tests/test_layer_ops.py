@@ -198,6 +198,30 @@ def test_gpu_attention_sinks_window(name, ctx, window):
         assert np.abs(got.cpu().numpy().astype(np.float32) - exp.astype(np.float32)).max() <= 2e-3 * np.abs(exp.astype(np.float32)).max() + 1e-5
 
 
+@pytest.mark.parametrize("name", ["prompt_full", "prompt_window"])
+def test_oracle_prompt_attention_vs_transformers(name):
+    """Every query of a 100-token prompt at once (causal mask, sinks, optional window) against transformers'
+    eager_attention_forward in fp32: pins the numpy prompt attention the GPU kernel is checked with."""
+    p = oracle_ref.prompt_attention_case(name)
+    got = oracle_ref.attn_prefill(p["q"], p["k"], p["v"], np.array([0, p["S"]], np.int32), p["D"] ** -0.5, p["sinks"], p["window"])
+    want = _g(f"layer_attn.{name}.npy")
+    assert np.abs(got.astype(np.float32) - want).max() <= 2e-3 * np.abs(want).max() + 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["prompt_full", "prompt_window"])
+def test_gpu_prompt_attention_vs_transformers(name):
+    from gpt_oss_vllm_amd import lib
+    cuda = torch.device("cuda:0")
+    p = oracle_ref.prompt_attention_case(name)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    out = lib.attn_prefill(dev(p["q"]), dev(p["k"]), dev(p["v"]), dev(np.array([0, p["S"]], np.int32)), p["S"],
+                           scale=p["D"] ** -0.5, sinks=dev(p["sinks"]), window=p["window"])
+    torch.cuda.synchronize()
+    want = _g(f"layer_attn.{name}.npy")
+    assert np.abs(out.cpu().numpy().astype(np.float32) - want).max() <= 2e-3 * np.abs(want).max() + 1e-5
+
+
 def _oai_case():
     Hs, FFs, Es, ks, Ts = 256, 192, 4, 2, 9
     lay = oracle_ref.synth_layer(oracle_ref.stream_seed(720), Es, Hs, FFs)
@@ -276,16 +300,12 @@ def test_gpu_plugin_swigluoai():
         method.apply(layer, torch.from_numpy(xs).to(cuda), torch.from_numpy(lg).to(cuda), top_k=2, activation="gelu")
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("name", ["sliding", "full"])
-def test_gpu_whole_decoder_layer_vs_transformers(name):
-    """200 prompt tokens are written into the paged cache through the layer's own norm / projection / rotary
-    kernels, then one new token goes through the whole layer; the result is the last row of transformers'
-    GptOssDecoderLayer run over the 201-token sequence in fp32 (sliding-window layer and full-attention layer)."""
+def _decoder_layer(name, max_tokens):
+    """(layer object, case dict) of a whole-decoder-layer case on cuda:0."""
     from gpt_oss_vllm_amd import layer, lib
     cuda = torch.device("cuda:0")
     p = oracle_ref.decoder_layer_case(name)
-    H_, FF_, E_, L = p["H"], p["FF"], p["E"], p["L"]
+    H_, FF_, E_ = p["H"], p["FF"], p["E"]
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
     w13_q, w13_a, w2_q, w2_a = [], [], [], []
     for e in range(E_):
@@ -298,8 +318,22 @@ def test_gpu_whole_decoder_layer_vs_transformers(name):
                    w13_q=torch.stack(w13_q), w13_absmax=torch.stack(w13_a), w2_q=torch.stack(w2_q), w2_absmax=torch.stack(w2_a),
                    b13=dev(np.concatenate([p["b13"][:, 0::2], p["b13"][:, 1::2]], axis=1)), b2=dev(p["b2"]))
     lyr = layer.GptOssDecodeLayer(weights, hidden=H_, heads=p["Hq"], kv_heads=p["Hkv"], head_dim=p["D"], ffn=FF_, experts=E_,
-                                  top_k=p["k"], max_tokens=1, window=p["window"] if name == "sliding" else 0,
+                                  top_k=p["k"], max_tokens=max_tokens, window=p["window"] if name == "sliding" else 0,
                                   act_mode=lib.ACT_SWIGLU_OAI)
+    return lyr, p
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["sliding", "full"])
+def test_gpu_whole_decoder_layer_vs_transformers(name):
+    """200 prompt tokens are written into the paged cache through the layer's own norm / projection / rotary
+    kernels, then one new token goes through the whole layer; the result is the last row of transformers'
+    GptOssDecoderLayer run over the 201-token sequence in fp32 (sliding-window layer and full-attention layer)."""
+    from gpt_oss_vllm_amd import layer
+    cuda = torch.device("cuda:0")
+    lyr, p = _decoder_layer(name, 1)
+    L = p["L"]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
     block_size = 16
     nblk = (L + 1 + block_size - 1) // block_size
     perm = np.random.default_rng(3).permutation(nblk).astype(np.int32)
@@ -318,3 +352,48 @@ def test_gpu_whole_decoder_layer_vs_transformers(name):
     got = (resid2.float() + moe_out.float()).cpu().numpy()[0]
     want = _g(f"layer_decoder.{name}.npy")
     assert np.abs(got - want).max() <= 5e-3 * np.abs(want).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["sliding", "full"])
+def test_gpu_prompt_through_decoder_layer_vs_transformers(name):
+    """The prompt pass of the layer: all 201 tokens at once (prompt attention kernel), every output row against
+    transformers' GptOssDecoderLayer; then the cache the pass left serves a decode step: token 201 repeated as a new
+    token at position 200 of a 200-token cache gives the prompt pass's own last row."""
+    from gpt_oss_vllm_amd import layer
+    cuda = torch.device("cuda:0")
+    lyr, p = _decoder_layer(name, 1)
+    S = p["L"] + 1
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    block_size = 16
+    nblk = (S + block_size - 1) // block_size
+    perm = np.random.default_rng(4).permutation(nblk).astype(np.int32)
+    kc = torch.zeros((nblk, block_size, p["Hkv"], p["D"]), dtype=torch.float16, device=cuda)
+    vc = torch.zeros_like(kc)
+    cos, sin = layer.rope_tables(512)
+    cos, sin = cos.to(cuda), sin.to(cuda)
+    slots = torch.tensor([int(perm[t // block_size]) * block_size + t % block_size for t in range(S)], dtype=torch.int64, device=cuda)
+    x = dev(p["x"])
+    resid2, moe_out = lyr.prefill(x, None, torch.arange(S, dtype=torch.int32, device=cuda), slots,
+                                  torch.tensor([0, S], dtype=torch.int32, device=cuda), S, kc, vc, cos, sin)
+    torch.cuda.synchronize()
+    got = (resid2.float() + moe_out.float()).cpu().numpy()
+    want = _g(f"layer_decoder_rows.{name}.npy")
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 5e-3 * np.abs(want).max()
+    # two prompts packed in one pass (the 201 tokens and their first 70) = each on its own
+    both = torch.cat([x, x[:70]])
+    pos2 = torch.cat([torch.arange(S), torch.arange(70)]).to(torch.int32).to(cuda)
+    no_slot = torch.full((S + 70,), -1, dtype=torch.int64, device=cuda)           # negative slot: not cached
+    r2, m2 = lyr.prefill(both, None, pos2, no_slot, torch.tensor([0, S, S + 70], dtype=torch.int32, device=cuda), S, kc, vc, cos, sin)
+    torch.cuda.synchronize()
+    got2 = (r2.float() + m2.float()).cpu().numpy()
+    assert np.abs(got2[:S] - got).max() <= 2e-3 * np.abs(got).max()
+    assert np.abs(got2[S:] - got[:70]).max() <= 2e-3 * np.abs(got).max()
+    # decode on the cache the prompt pass filled
+    resid_d, moe_d = lyr.forward(x[S - 1:].contiguous(), None, torch.tensor([S - 1], dtype=torch.int32, device=cuda),
+                                 slots[S - 1:].contiguous(), dev(perm[None, :].copy()),
+                                 torch.tensor([S], dtype=torch.int32, device=cuda), kc, vc, cos, sin, max_ctx=S)
+    torch.cuda.synchronize()
+    dec = (resid_d.float() + moe_d.float()).cpu().numpy()[0]
+    assert np.abs(dec - got[-1]).max() <= 2e-3 * np.abs(got[-1]).max()
