@@ -299,6 +299,64 @@ def full_layer_leg(lib, main_step, batch, ctx, layers, device, steps, warmup):
             "dense_projection_bytes_per_step": dense_bytes}
 
 
+def full_layer_prompt_leg(lib, main_step, tokens, layers, device, reps=3):
+    """The whole decoder stack over one prompt of `tokens` tokens (every layer: norm, q/k/v projection on the tiled dense
+    kernel, rotary + cache write, prompt attention with sinks, o projection, norm, router, NF4 experts with gpt-oss's
+    activation and biases), one HIP graph."""
+    from gpt_oss_vllm_amd import layer as layer_mod
+    g = torch.Generator(device=device)
+    g.manual_seed(4343)
+    rnd = lambda shape, std: (torch.randn(shape, device=device, generator=g) * std).half()
+    T = tokens
+    nblk = (T + BLOCK - 1) // BLOCK
+    kc = torch.zeros((nblk, BLOCK, HKV, D), dtype=torch.float16, device=device)      # one cache, reused by the layers (synthetic)
+    vc = torch.zeros_like(kc)
+    positions = torch.arange(T, dtype=torch.int32, device=device)
+    slots = torch.arange(T, dtype=torch.int64, device=device)
+    starts = torch.tensor([0, T], dtype=torch.int32, device=device)
+    cos, sin = layer_mod.rope_tables(T)
+    cos, sin = cos.to(device), sin.to(device)
+    stack = []
+    for li in range(layers):
+        src = main_step.L[li]
+        w = dict(ln1=rnd((H,), 0.1) + 1, ln2=rnd((H,), 0.1) + 1, wqkv=rnd(((HQ + 2 * HKV) * D, H), 0.02), bqkv=rnd(((HQ + 2 * HKV) * D,), 0.02),
+                 wo=rnd((H, HQ * D), 0.02), bo=rnd((H,), 0.02), sinks=rnd((HQ,), 1.0), router_w=src["wr"], router_b=rnd((E,), 0.02),
+                 w13_q=src["w13_q"], w13_absmax=src["w13_a"], w2_q=src["w2_q"], w2_absmax=src["w2_a"],
+                 b13=rnd((E, 2 * FF), 0.02), b2=rnd((E, H), 0.02))
+        stack.append(layer_mod.GptOssDecodeLayer(w, hidden=H, heads=HQ, kv_heads=HKV, head_dim=D, ffn=FF, experts=E, top_k=TOPK,
+                                                 max_tokens=1, window=128 if li % 2 == 0 else 0, act_mode=lib.ACT_SWIGLU_OAI))
+    x0 = rnd((T, H), 1.0)
+
+    def run():
+        resid, delta = x0, None
+        for lyr in stack:
+            resid, delta = lyr.prefill(resid, delta, positions, slots, starts, T, kc, vc, cos, sin)
+        return resid, delta
+
+    run()
+    torch.cuda.synchronize()
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        run()
+    torch.cuda.current_stream().wait_stream(s_)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run()
+    graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        graph.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    dense_flops = 2.0 * T * H * ((HQ + 2 * HKV) * D + HQ * D)
+    return {"value": T / dt, "unit": "tokens/s", "tokens": T, "ms_per_layer": dt / layers * 1e3,
+            "what": f"{layers} whole decoder layers over one {T}-token prompt, one HIP graph",
+            "dense_projection_tflop_per_layer": dense_flops / 1e12}
+
+
 def prefill_leg(lib, main_step, device, tokens, reps=3):
     """The same experts fed a prefill-sized batch (configs[4] of BASELINE.json is an 8k-token prefill): per layer router top-k
     + fused NF4 MoE, where the library picks its kernel for many tokens per expert (256-token tiles, weights
@@ -524,6 +582,8 @@ def main():
         result["prefill"] = prefill_leg(lib, main_step, device, a.prefill_tokens)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
+    if rank == 0 and world == 1 and a.full_layer_leg and a.prefill_tokens > 0:
+        result["full_decoder_stack_prompt"] = full_layer_prompt_leg(lib, main_step, a.prefill_tokens, a.layers, device)
     if rank == 0 and world == 1 and a.full_layer_leg:
         result["full_decoder_stack"] = [full_layer_leg(lib, main_step, b, a.ctx, a.layers, device, a.steps, a.warmup)
                                         for b in (a.batch_per_gpu, 1)]

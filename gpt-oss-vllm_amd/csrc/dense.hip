@@ -1,4 +1,5 @@
-// Small-batch dense projection y = x W^T + b (+ residual) for decode: fp16 in, fp32 accumulate, fp16 out.
+// Dense projection y = x W^T + b (+ residual): fp16 in, fp32 accumulate, fp16 out.  This file: the entry point and the
+// small-batch (decode) kernel; from 128 tokens on the entry point hands over to the tiled kernel of dense_tile.hip.
 // At <= 32 tokens the product is a stream of W through the chip once (2 bytes per weight): HBM-bound, so the kernel
 // is built like the MoE weight streamer, not like a tiled GEMM.  Tokens sit on the N side of v_mfma_f32_16x16x32_f16.
 //
@@ -123,6 +124,11 @@ static int launch_dense(const half_t* x, const half_t* w, const half_t* bias, co
     return 0;
 }
 
+// many tokens: the tiled kernel of dense_tile.hip
+int launch_dense_tile(const half_t* x, const half_t* w, const half_t* bias, const half_t* resid, int T, int N, int K,
+                      half_t* out, int cus, hipStream_t st);
+constexpr int DENSE_TILE_MIN_T = 128;   // from here on re-streaming W once per 32 tokens costs more than tiling
+
 }  // namespace m355
 
 using namespace m355;
@@ -144,6 +150,7 @@ extern "C" int m355_linear_f16(const void* x_f16, int T, const void* w_f16, cons
     hipStream_t st = (hipStream_t)stream;
     const half_t *x = (const half_t*)x_f16, *w = (const half_t*)w_f16, *b = (const half_t*)bias_f16, *r = (const half_t*)resid_f16;
     half_t* out = (half_t*)out_f16;
+    if (T >= DENSE_TILE_MIN_T) return launch_dense_tile(x, w, b, r, T, N, K, out, cus, st);
     const bool small_k = K <= 64 * DENSE_KPARTS * 6;
     // 32 tokens per pass; more tokens re-stream W once per pass (decode batches above 32 are the exception here)
     for (int t0 = 0; t0 < T; t0 += 32) {

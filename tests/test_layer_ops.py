@@ -112,7 +112,10 @@ def test_gpu_rope_kv_write():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,N,K,bias,resid", [(1, 5120, 2880, True, False), (32, 2880, 4096, True, True),
-                                              (40, 64, 256, True, True), (17, 48, 64, False, False), (5, 16, 3072, False, True)])
+                                              (40, 64, 256, True, True), (17, 48, 64, False, False), (5, 16, 3072, False, True),
+                                              # from 128 tokens on: the tiled kernel (whole and ragged token tiles, row groups)
+                                              (128, 5120, 2880, True, False), (300, 2880, 4096, True, True),
+                                              (1000, 48, 64, False, True), (2049, 272, 128, True, True), (257, 512, 192, False, False)])
 def test_gpu_linear_f16(T, N, K, bias, resid):
     """q/k/v and o projection shapes of gpt-oss-20b plus ragged small ones, against an fp32 matmul of the same fp16
     inputs (tolerance: fp16 rounding of the result plus fp32 summation order)."""
@@ -134,6 +137,30 @@ def test_gpu_linear_f16(T, N, K, bias, resid):
     torch.cuda.synchronize()
     err = np.abs(got.cpu().numpy().astype(np.float32) - want.astype(np.float32)).max()
     assert err <= 2e-3 * np.abs(want.astype(np.float32)).max() + 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_linear_f16_prompt_size():
+    """8192 tokens through the q/k/v projection shape (256-token tiles): sampled tokens against an fp32 matmul, and
+    the result is the same whatever else shares the launch (a token's row alone through the small-batch kernel)."""
+    from gpt_oss_vllm_amd import lib
+    cuda = torch.device("cuda:0")
+    T, N, K = 8192, 5120, 2880
+    g = torch.Generator(device=cuda)
+    g.manual_seed(5)
+    x = torch.randn((T, K), device=cuda, generator=g).half()
+    w = (torch.randn((N, K), device=cuda, generator=g) * 0.05).half()
+    b = torch.randn((N,), device=cuda, generator=g).half()
+    r = torch.randn((T, N), device=cuda, generator=g).half()
+    got = lib.linear_f16(x, w, b, r)
+    sample = [0, 31, 32, 255, 256, 4097, 8000, 8191]
+    small = lib.linear_f16(x[sample].contiguous(), w, b, r[sample].contiguous())
+    torch.cuda.synchronize()
+    xs, ws = x[sample].cpu().numpy().astype(np.float32), w.cpu().numpy().astype(np.float32)
+    want = ((xs @ ws.T + b.cpu().numpy().astype(np.float32)).astype(np.float16) + r[sample].cpu().numpy()).astype(np.float32)
+    tol = 2e-3 * np.abs(want).max() + 1e-5
+    assert np.abs(got[sample].cpu().numpy().astype(np.float32) - want).max() <= tol
+    assert np.abs(got[sample].float().cpu().numpy() - small.float().cpu().numpy()).max() <= tol
 
 
 ATTN_CASES = (("sinks_full", 300, 0), ("sinks_window", 300, 128), ("sinks_short", 70, 128))
