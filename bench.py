@@ -98,35 +98,65 @@ class DecodeStep:
             self.L.append(lay)
         self.graph = None
 
-    def run_eager(self):
+    def pieces(self):
+        """The launch sequence of a step as (is_collective, callable) pieces, adjacent kernel-only pieces merged: with
+        experts sharded, a layer is [attention, router, pack] -> dispatch all-to-all -> [unpack, experts] -> combine
+        all-to-all -> [reduce], and the reduce joins the next layer's first piece."""
         lib = self.lib
+        seq = []
+
+        def add(is_coll, fn):
+            if not is_coll and seq and not seq[-1][0]:
+                prev = seq[-1][1]
+                seq[-1] = (False, lambda prev=prev, fn=fn: (prev(), fn()))
+            else:
+                seq.append((is_coll, fn))
+
         for lay in self.L:
-            lib.paged_attn_decode(lay["q"], lay["kc"], lay["vc"], self.block_tables, self.ctx_lens, max_ctx=self.ctx,
-                                  scale=D ** -0.5, out=lay["attn_out"])
             ep = lay["ep"]
+            add(False, lambda lay=lay: lib.paged_attn_decode(lay["q"], lay["kc"], lay["vc"], self.block_tables, self.ctx_lens,
+                                                             max_ctx=self.ctx, scale=D ** -0.5, out=lay["attn_out"]))
             if ep.world == 1 and not ep.force_exchange:
                 # router and experts in one library call (up to 8 tokens gate_up computes the router itself)
-                lib.moe_nf4_forward_routed(lay["x"], lay["wr"], None, TOPK, *ep.weights, E_local=ep.epr, e_first=0, H=H, FF=FF,
-                                           ids=lay["ids"], w=lay["w"], workspace=ep.workspace, out=lay["out"], flags=ep.flags)
+                add(False, lambda lay=lay, ep=ep: lib.moe_nf4_forward_routed(
+                    lay["x"], lay["wr"], None, TOPK, *ep.weights, E_local=ep.epr, e_first=0, H=H, FF=FF, ids=lay["ids"],
+                    w=lay["w"], workspace=ep.workspace, out=lay["out"], flags=ep.flags))
             else:
-                lib.router_topk(lay["x"], lay["wr"], None, TOPK, ids=lay["ids"], w=lay["w"])
-                ep.forward(lay["x"], lay["ids"], lay["w"], out=lay["out"])
+                add(False, lambda lay=lay, ep=ep: (lib.router_topk(lay["x"], lay["wr"], None, TOPK, ids=lay["ids"], w=lay["w"]),
+                                                   ep.pack(lay["x"], lay["ids"], lay["w"])))
+                add(True, ep.dispatch)
+                add(False, ep.experts)
+                add(True, ep.combine)
+                add(False, lambda lay=lay, ep=ep: ep.finish(lay["out"]))
+        return seq
 
-    def capture(self):
+    def run_eager(self):
+        for _, fn in self.pieces():
+            fn()
+
+    def _capture_one(self, fn):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g
+
+    def _side_stream_pass(self):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self.run_eager()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self.run_eager()
-        self.graph = g
+
+    def capture(self):
+        """The whole step as one HIP graph (collectives included when experts are sharded)."""
+        self._side_stream_pass()
+        self.graph = [(False, self._capture_one(self.run_eager).replay)]
 
     def step(self):
         if self.graph is not None:
-            self.graph.replay()
+            for _, fn in self.graph:
+                fn()
         else:
             self.run_eager()
 
@@ -521,9 +551,18 @@ def main():
                            absmax=a.absmax)
     main_step.run_eager()          # first call sets kernel attributes; must precede graph capture
     torch.cuda.synchronize()
-    use_graph = ((world == 1 and not a.force_dist) or a.graph_dist) and not a.eager
-    if use_graph:
-        main_step.capture()
+    sharded = world > 1 or a.force_dist
+    # With experts sharded the step is launched call by call: --graph-dist captures it whole, collectives included, which
+    # has only been exercised on one rank.  (One graph per run of kernels between two collectives was measured on one
+    # rank and is slower than plain launches: 3.98 against 3.74 ms per step, a graph launch costs more than the three or
+    # four kernel launches it replaces.)
+    use_graph = (not sharded or a.graph_dist) and not a.eager
+
+    def capture(stepper):
+        if use_graph:
+            stepper.capture()
+
+    capture(main_step)
     dt = timed(main_step, a.steps, a.warmup, world)
     tokens = a.batch_per_gpu * world
     result = {
@@ -543,14 +582,12 @@ def main():
 
     if not a.no_bs1:
         # configs[1] of BASELINE.json: bs=1 greedy decode, seq_len 256 (per GPU when N > 1)
-        del main_step.graph
         main_step.graph = None
         bs1 = DecodeStep(lib, ep_mod, 1, a.ctx, a.layers, rank, world, device, weights_from=main_step,
                          force_exchange=a.force_dist)
         bs1.run_eager()
         torch.cuda.synchronize()
-        if use_graph:
-            bs1.capture()
+        capture(bs1)
         dt1 = timed(bs1, a.steps, a.warmup, world)
         result["bs1"] = {"value": world * a.steps / dt1, "unit": "tokens/s", "ms_per_step": dt1 / a.steps * 1e3,
                          "workload": f"bs=1 per GPU (global {world}), ctx {a.ctx}: BASELINE configs[1]" if world == 1

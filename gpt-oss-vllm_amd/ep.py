@@ -105,12 +105,30 @@ class ExpertParallelMoE:
         if N == 1 and not self.force_exchange:
             self.ops.moe(x, ids, w, self.weights, self.epr, 0, H, self.FF, self.workspace, out, self.flags)
             return out
-        self.ops.pack(x, ids, w, N, self.epr, self.send)
+        self.pack(x, ids, w)
+        self.dispatch()
+        self.experts()
+        self.combine()
+        return self.finish(out)
+
+    # The five pieces of forward(), callable one by one: pack / experts / finish launch kernels only (a caller may capture
+    # them in HIP graphs), dispatch / combine are the two collectives.
+
+    def pack(self, x, ids, w):
+        self.ops.pack(x, ids, w, self.world, self.epr, self.send)
+
+    def dispatch(self):
         self.exchange(self.recv, self.send)
-        self.ops.unpack(self.recv, N * T, k, H, self.x_all, self.ids_all, self.w_all)
+
+    def experts(self):
         # this rank sees the N * T token slots of all ranks but only the pairs routed to its experts
-        self.ops.moe(self.x_all, self.ids_all, self.w_all, self.weights, self.epr, self.e_first, H, self.FF,
+        self.ops.unpack(self.recv, self.world * self.T, self.k, self.H, self.x_all, self.ids_all, self.w_all)
+        self.ops.moe(self.x_all, self.ids_all, self.w_all, self.weights, self.epr, self.e_first, self.H, self.FF,
                      self.workspace, self.partial, self.flags | self.shard_flags)
+
+    def combine(self):
         self.exchange(self.back.view(-1), self.partial.view(-1))
-        self.ops.reduce(self.back, N, T, H, out)
+
+    def finish(self, out):
+        self.ops.reduce(self.back, self.world, self.T, self.H, out)
         return out
