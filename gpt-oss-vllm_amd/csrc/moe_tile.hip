@@ -302,6 +302,25 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
         if (b < NB) iteration(b, afA, afB);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last iterations' DMA re-reads the last block)
     };
+    // A wave whose pairs all lie past the last one (the last row group of R = 32 * NP rows when NP is no multiple of the
+    // pairs per workgroup) brings its share of the activations and keeps the barriers, nothing else: the workgroup then
+    // runs at the pace of its live waves.
+    auto idle_loop = [&](auto full_tag) {
+#pragma unroll
+        for (int k = 0; k < TG_XI; k++) dma_piece(full_tag, k, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int b = 0; b < NB; b++) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < TG_XI; k++) dma_piece(full_tag, k, b + 1, b + 2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (p0 >= NP) {
+        if (ntt == TG_TOKEN_TILES) idle_loop(std::true_type{});
+        else idle_loop(std::false_type{});
+        return;
+    }
     if (ntt == TG_TOKEN_TILES) main_loop(std::true_type{});
     else main_loop(std::false_type{});
 
