@@ -1,44 +1,50 @@
 // Paged-attention decode for grouped-query heads (8 query heads per KV head, head size 64).
 // HBM-bound on the KV read: 2 * Hkv * D * 2 bytes per cached token per sequence.
 //
-// One workgroup (4 waves) serves one (sequence, KV head, 256-token partition): the 8 query heads of the
-// group share every K and V row that is fetched.  A lane is (token slot ts = lane/8, 16-byte piece dc =
-// lane%8), so a wave-load covers 8 whole 128-byte rows.  Pass 1 streams K and leaves the scaled scores
-// in LDS, the softmax numerators are formed once per partition (no running rescale), pass 2 streams V.
-// Longer contexts use several partitions plus a small merge kernel.
+// One workgroup (4 waves) serves one (sequence, KV head, 256-token partition); a wave owns 64 of its tokens.  Both
+// products run on the matrix cores (v_mfma_f32_16x16x32_f16) with the 8 query heads on the 16-wide N side, so the 8
+// heads of the group share every K and V row that is fetched:
+//   S^T[token][head] = K Q^T    A = K rows straight from global memory: lane (r, g) loads the 32 contiguous bytes
+//                               K[token r][16 g .. 16 g + 15] (a wave-load covers 16 whole 128-byte rows); the first
+//                               MFMA takes the lower 8 columns, the second the upper 8, and Q is laid out the same way
+//                               (a dot product does not care in which order its terms are summed).
+//   O^T[d][head] += V^T P^T     the scores of a lane (head n, tokens 4 g .. 4 g + 3 of each 16-token tile), turned into
+//                               softmax numerators and rounded to fp16 where they sit, ARE the B operand (tokens of two
+//                               tiles in the order the lanes hold them); V^T in the same token order comes from the
+//                               wave's V rows in LDS through ds_read_b64_tr_b16 (hardware transpose read).
+// Each wave normalises against its own maximum; the four waves (and, for longer contexts, the partitions, in a small
+// merge kernel) are merged with the usual exp(m_w - m) factors.
 #include "common.h"
 
 namespace m355 {
 
 constexpr int ATT_THREADS = 256;
-constexpr int ATT_PART = 256;   // tokens per partition
-constexpr int ATT_G = 8;        // query heads per KV head
+constexpr int ATT_WAVES = ATT_THREADS / 64;
+constexpr int ATT_PART = 256;                    // tokens per partition
+constexpr int ATT_WTOK = ATT_PART / ATT_WAVES;   // tokens per wave
+constexpr int ATT_TILES = ATT_WTOK / 16;         // 16-token MFMA tiles per wave
+constexpr int ATT_G = 8;                         // query heads per KV head
 constexpr int ATT_D = 64;
+static_assert(ATT_TILES % 2 == 0, "the second product takes the tiles in pairs");
 
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-// sum over the 8 lanes that share a token slot (lane%8 varies): quad xor 1, quad xor 2, half-row mirror
-__device__ __forceinline__ float sum8(float v) {
-    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141>(v);   // row_half_mirror
-    return v;
-}
+typedef short att_short4_t __attribute__((ext_vector_type(4)));
+typedef short att_short8_t __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) att_short4_t att_lds_s4_t;
 
 __global__ __launch_bounds__(ATT_THREADS) void paged_attn_decode_kernel(
     const half_t* __restrict__ q, const half_t* __restrict__ kc, const half_t* __restrict__ vc,
     const int32_t* __restrict__ block_tables, const int32_t* __restrict__ ctx_lens, int Hq, int Hkv, int block_size,
     int max_blocks, float scale, int nparts, float* __restrict__ part_o, float* __restrict__ part_ml,
     half_t* __restrict__ out, const half_t* __restrict__ sinks, int window) {
-    __shared__ __attribute__((aligned(16))) float sc[ATT_PART * ATT_G];   // [token][head]
-    __shared__ __attribute__((aligned(16))) float wred[4 * ATT_G * ATT_D];
-    __shared__ float m_s[ATT_G], l_s[ATT_G];
+    // V rows of the partition, 128 bytes each; the 32-byte piece p of row t sits at piece position p ^ ((t >> 1) & 3),
+    // so the 8 rows x 32 bytes that half a wave reads transposed cover every bank once
+    __shared__ __attribute__((aligned(16))) unsigned char vs[ATT_PART * 128];
+    __shared__ __attribute__((aligned(16))) float po[ATT_WAVES][ATT_G][ATT_D];   // the waves' unnormalised outputs
+    __shared__ float pm[ATT_WAVES][ATT_G], pl[ATT_WAVES][ATT_G];                 // their maxima and denominators
 
     const int b = blockIdx.x, hk = blockIdx.y, part = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ts = lane >> 3, dc = lane & 7;
+    const int r = lane & 15, g = lane >> 4;
     const int L = ctx_lens[b];
     const int t0 = part * ATT_PART;
     // sliding window: the query (position L - 1) sees keys L - window .. L - 1; tokens below `first` are masked
@@ -63,127 +69,118 @@ __global__ __launch_bounds__(ATT_THREADS) void paged_attn_decode_kernel(
         return;
     }
 
-    // this lane's 8 columns of the 8 query heads
-    u32x4_t qv[ATT_G];
-#pragma unroll
-    for (int h = 0; h < ATT_G; h++) qv[h] = reinterpret_cast<const u32x4_t*>(q + (ob + h) * ATT_D)[dc];
-
+    // K and V rows: lane (r, g) takes bytes 32 g .. 32 g + 31 of token r of each of the wave's tiles (tokens past the
+    // end re-read the last one and are masked below).  K and V are requested together: one latency, not two.
     const int32_t* bt = block_tables + (int64_t)b * max_blocks;
-    constexpr int ITERS = ATT_PART / 32;
     const int64_t row_stride = (int64_t)Hkv * ATT_D;
-
-    // ---- pass 1: scores ----  (the V rows are requested together with the K rows: one latency, not two)
-    u32x4_t vv[ITERS];
-    {
-        u32x4_t kv[ITERS];
+    u32x4_t ka[ATT_TILES], kb[ATT_TILES], va[ATT_TILES], vb[ATT_TILES];
 #pragma unroll
-        for (int it = 0; it < ITERS; it++) {
-            const int tl = min(it * 32 + wave * 8 + ts, npt - 1);
-            const int t = t0 + tl;
-            const int blk = bt[t / block_size];
-            const int64_t row = ((int64_t)blk * block_size + t % block_size) * row_stride + hk * ATT_D;
-            kv[it] = reinterpret_cast<const u32x4_t*>(kc + row)[dc];
-            vv[it] = reinterpret_cast<const u32x4_t*>(vc + row)[dc];
-        }
-#pragma unroll
-        for (int it = 0; it < ITERS; it++) {
-            const int tl = it * 32 + wave * 8 + ts;
-            float mine = 0.f;
-#pragma unroll
-            for (int h = 0; h < ATT_G; h++) {
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    s = __builtin_amdgcn_fdot2(as_half2(qv[h][j]), as_half2(kv[it][j]), s, false);
-                s = sum8(s);
-                if (dc == h) mine = s;
-            }
-            sc[tl * ATT_G + dc] = (tl < npt && tl >= first) ? mine * scale : -INFINITY;
-        }
+    for (int j = 0; j < ATT_TILES; j++) {
+        const int t = t0 + min(wave * ATT_WTOK + j * 16 + r, npt - 1);
+        const int blk = bt[t / block_size];
+        const int64_t row = ((int64_t)blk * block_size + t % block_size) * row_stride + hk * ATT_D + 16 * g;
+        ka[j] = reinterpret_cast<const u32x4_t*>(kc + row)[0];
+        kb[j] = reinterpret_cast<const u32x4_t*>(kc + row)[1];
+        va[j] = reinterpret_cast<const u32x4_t*>(vc + row)[0];
+        vb[j] = reinterpret_cast<const u32x4_t*>(vc + row)[1];
     }
-    __syncthreads();
+    // Q as the B operand: lane (n, g) holds Q[head n][16 g .. 16 g + 15]; columns 8..15 of the product are padding
+    u32x4_t qa = {0u, 0u, 0u, 0u}, qb = {0u, 0u, 0u, 0u};
+    if (r < ATT_G) {
+        const u32x4_t* qp = reinterpret_cast<const u32x4_t*>(q + (ob + r) * ATT_D + 16 * g);
+        qa = qp[0];
+        qb = qp[1];
+    }
 
-    // ---- softmax numerators: 32 threads per head ----
-    {
-        const int h = tid >> 5, i = tid & 31;
-        float v[ATT_PART / 32];
-        float mx = -INFINITY;
+    // ---- scores: lane (n, g) gets head n, tokens 4 g .. 4 g + 3 of each tile ----
+    float4_t sc[ATT_TILES];
 #pragma unroll
-        for (int u = 0; u < ATT_PART / 32; u++) {
-            v[u] = sc[(u * 32 + i) * ATT_G + h];
-            mx = fmaxf(mx, v[u]);
+    for (int j = 0; j < ATT_TILES; j++) {
+        const float4_t z = {0.f, 0.f, 0.f, 0.f};
+        sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, ka[j]), __builtin_bit_cast(half8_t, qa), z, 0, 0, 0);
+        sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, kb[j]), __builtin_bit_cast(half8_t, qb), sc[j], 0, 0, 0);
+    }
+    // ---- the wave's V rows go to LDS (each wave reads back only its own rows) ----
+#pragma unroll
+    for (int j = 0; j < ATT_TILES; j++) {
+        const int lrow = wave * ATT_WTOK + j * 16 + r;
+        unsigned char* dst = vs + lrow * 128 + ((g ^ ((lrow >> 1) & 3)) << 5);
+        *reinterpret_cast<u32x4_t*>(dst) = va[j];
+        *reinterpret_cast<u32x4_t*>(dst + 16) = vb[j];
+    }
+
+    // ---- softmax numerators against the wave's own maximum ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < ATT_TILES; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int tl = wave * ATT_WTOK + j * 16 + 4 * g + i;
+            sc[j][i] = (tl < npt && tl >= first) ? sc[j][i] * scale : -INFINITY;
+            mx = fmaxf(mx, sc[j][i]);
         }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_use = (mx == -INFINITY) ? 0.f : mx;   // every token of this wave masked: all terms are 0
+    float sum = 0.f;
+    half8_t pf[ATT_TILES / 2];   // element e of pair c: token 4 g + (e & 3) of tile 2 c + (e >> 2)
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        float sum = 0.f;
+    for (int j = 0; j < ATT_TILES; j++)
 #pragma unroll
-        for (int u = 0; u < ATT_PART / 32; u++) {
-            const float pv = __expf(v[u] - mx);
+        for (int i = 0; i < 4; i++) {
+            const float pv = __expf(sc[j][i] - m_use);
             sum += pv;
-            sc[(u * 32 + i) * ATT_G + h] = pv;
+            pf[j >> 1][(j & 1) * 4 + i] = (half_t)pv;
         }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    __syncthreads();   // the V rows are in LDS
+
+    // ---- O^T[d][head] += V^T P^T: lane (n, g) gets head n, columns 16 dt + 4 g .. + 3 ----
+    // transposed read: within a 16-lane group, lane 4 a + c supplies row a, columns 4 c .. 4 c + 3 of a block of 4 tokens x
+    // 16 columns and lane i receives column i of the 4 tokens
+    float4_t o[ATT_D / 16];
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        if (i == 0) { m_s[h] = mx; l_s[h] = sum; }
+    for (int dt = 0; dt < ATT_D / 16; dt++) o[dt] = float4_t{0.f, 0.f, 0.f, 0.f};
+    const int ta = r >> 2, tc = r & 3;
+#pragma unroll
+    for (int c = 0; c < ATT_TILES / 2; c++) {
+        const int row0 = wave * ATT_WTOK + 2 * c * 16 + 4 * g + ta;   // its partner of the next tile is row0 + 16
+        const int swz = (row0 >> 1) & 3;                              // (the same for row0 + 16)
+#pragma unroll
+        for (int dt = 0; dt < ATT_D / 16; dt++) {
+            unsigned char* src = vs + row0 * 128 + ((dt ^ swz) << 5) + 8 * tc;
+            const att_short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4_t*)(src));
+            const att_short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s4_t*)(src + 16 * 128));
+            const att_short8_t av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, av), pf[c], o[dt], 0, 0, 0);
+        }
+    }
+    if (r < ATT_G) {
+#pragma unroll
+        for (int dt = 0; dt < ATT_D / 16; dt++) *reinterpret_cast<float4_t*>(&po[wave][r][16 * dt + 4 * g]) = o[dt];
+        if (g == 0) { pm[wave][r] = mx; pl[wave][r] = sum; }
     }
     __syncthreads();
 
-    // ---- pass 2: o[h][d] += p[h][t] * v[t][d] ----
-    float o[ATT_G][8];
-#pragma unroll
-    for (int h = 0; h < ATT_G; h++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) o[h][j] = 0.f;
-    {
-#pragma unroll
-        for (int it = 0; it < ITERS; it++) {
-            const int tl = it * 32 + wave * 8 + ts;
-            const float4_t p0 = *reinterpret_cast<const float4_t*>(&sc[tl * ATT_G]);       // 0 for masked tokens
-            const float4_t p1 = *reinterpret_cast<const float4_t*>(&sc[tl * ATT_G + 4]);
-            float vf[8];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const half2_t h2 = as_half2(vv[it][j]);
-                vf[2 * j] = (float)h2[0];
-                vf[2 * j + 1] = (float)h2[1];
-            }
-#pragma unroll
-            for (int h = 0; h < ATT_G; h++) {
-                const float ph = (h < 4) ? p0[h & 3] : p1[h & 3];
-#pragma unroll
-                for (int j = 0; j < 8; j++) o[h][j] += ph * vf[j];
-            }
-        }
-    }
-    // sum over the 8 token slots of the wave (lane bits 3,4,5), then over the 4 waves through LDS
-#pragma unroll
-    for (int h = 0; h < ATT_G; h++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            float v = o[h][j];
-            v += dpp_mov<0x128>(v);        // row_ror:8  (lane ^ 8 within the 16-lane row)
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            o[h][j] = v;
-        }
-    if (ts == 0) {
-#pragma unroll
-        for (int h = 0; h < ATT_G; h++) {
-            float4_t a = {o[h][0], o[h][1], o[h][2], o[h][3]}, c = {o[h][4], o[h][5], o[h][6], o[h][7]};
-            *reinterpret_cast<float4_t*>(&wred[(wave * ATT_G + h) * ATT_D + dc * 8]) = a;
-            *reinterpret_cast<float4_t*>(&wred[(wave * ATT_G + h) * ATT_D + dc * 8 + 4]) = c;
-        }
-    }
-    __syncthreads();
+    // ---- merge the waves ----
     for (int i = tid; i < ATT_G * ATT_D; i += ATT_THREADS) {
         const int h = i / ATT_D, d = i % ATT_D;
-        const float tot = wred[(0 * ATT_G + h) * ATT_D + d] + wred[(1 * ATT_G + h) * ATT_D + d] +
-                          wred[(2 * ATT_G + h) * ATT_D + d] + wred[(3 * ATT_G + h) * ATT_D + d];
+        float m = -INFINITY;
+#pragma unroll
+        for (int wv = 0; wv < ATT_WAVES; wv++) m = fmaxf(m, pm[wv][h]);
+        float tot = 0.f, l = 0.f;   // m is finite: at least one token of the partition is visible
+#pragma unroll
+        for (int wv = 0; wv < ATT_WAVES; wv++) {
+            const float f = __expf(pm[wv][h] - m);   // 0 for a wave with nothing visible
+            tot += f * po[wv][h][d];
+            l += f * pl[wv][h];
+        }
         if (nparts == 1) {
             // a sink is one more logit in the softmax denominator (its value row is dropped)
-            float num = tot, den = l_s[h];
+            float num = tot, den = l;
             if (sinks) {
-                const float sk = (float)sinks[hk * ATT_G + h], m2 = fmaxf(m_s[h], sk), f = __expf(m_s[h] - m2);
+                const float sk = (float)sinks[hk * ATT_G + h], m2 = fmaxf(m, sk), f = __expf(m - m2);
                 num *= f;
                 den = den * f + __expf(sk - m2);
             }
@@ -191,8 +188,8 @@ __global__ __launch_bounds__(ATT_THREADS) void paged_attn_decode_kernel(
         } else {
             part_o[((ob + h) * nparts + part) * ATT_D + d] = tot;
             if (d == 0) {
-                part_ml[((ob + h) * nparts + part) * 2 + 0] = m_s[h];
-                part_ml[((ob + h) * nparts + part) * 2 + 1] = l_s[h];
+                part_ml[((ob + h) * nparts + part) * 2 + 0] = m;
+                part_ml[((ob + h) * nparts + part) * 2 + 1] = l;
             }
         }
     }
