@@ -39,7 +39,9 @@ __global__ __launch_bounds__(ATT_THREADS) void paged_attn_decode_kernel(
     // V rows of the partition, 128 bytes each; the 32-byte piece p of row t sits at piece position p ^ ((t >> 1) & 3),
     // so the 8 rows x 32 bytes that half a wave reads transposed cover every bank once
     __shared__ __attribute__((aligned(16))) unsigned char vs[ATT_PART * 128];
-    __shared__ __attribute__((aligned(16))) float po[ATT_WAVES][ATT_G][ATT_D];   // the waves' unnormalised outputs
+    // a wave's unnormalised output [head][column] takes the place of its V rows once it has read them (LDS serves a
+    // wave's instructions in order)
+    auto po = [&](int wv, int h) -> float* { return reinterpret_cast<float*>(vs + wv * ATT_WTOK * 128) + h * ATT_D; };
     __shared__ float pm[ATT_WAVES][ATT_G], pl[ATT_WAVES][ATT_G];                 // their maxima and denominators
 
     const int b = blockIdx.x, hk = blockIdx.y, part = blockIdx.z;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(ATT_THREADS) void paged_attn_decode_kernel(
     }
     if (r < ATT_G) {
 #pragma unroll
-        for (int dt = 0; dt < ATT_D / 16; dt++) *reinterpret_cast<float4_t*>(&po[wave][r][16 * dt + 4 * g]) = o[dt];
+        for (int dt = 0; dt < ATT_D / 16; dt++) *reinterpret_cast<float4_t*>(po(wave, r) + 16 * dt + 4 * g) = o[dt];
         if (g == 0) { pm[wave][r] = mx; pl[wave][r] = sum; }
     }
     __syncthreads();
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(ATT_THREADS) void paged_attn_decode_kernel(
 #pragma unroll
         for (int wv = 0; wv < ATT_WAVES; wv++) {
             const float f = __expf(pm[wv][h] - m);   // 0 for a wave with nothing visible
-            tot += f * po[wv][h][d];
+            tot += f * po(wv, h)[d];
             l += f * pl[wv][h];
         }
         if (nparts == 1) {
