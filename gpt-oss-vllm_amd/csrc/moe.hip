@@ -754,7 +754,10 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
 }
 
 // out[t][c] = sum over the token's local pairs, in k order.  FP16 mode rounds as the reference's fp16
-// tensors do: w -> fp16, product -> fp16, running sum -> fp16.
+// tensors do: w -> fp16, product -> fp16, running sum -> fp16.  The pairs are taken KB at a time: their positions and
+// weights are requested together, then their y rows together, and only the arithmetic runs in k order, so a batch
+// costs two memory round trips instead of two per pair.
+template <int KB>
 __global__ __launch_bounds__(256) void moe_combine_kernel(const half_t* __restrict__ y, const int32_t* __restrict__ inv,
                                                           const float* __restrict__ w, int H, int k_top, int fp16_mode,
                                                           half_t* __restrict__ out) {
@@ -764,21 +767,33 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const half_t* __restri
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) acc[j] = 0.f;
-        for (int kk = 0; kk < k_top; kk++) {
-            const int pos = inv[t * k_top + kk];
-            if (pos < 0) continue;
-            const half8_t yv = reinterpret_cast<const half8_t*>(y + (int64_t)pos * H)[c];
-            const float wf = w[t * k_top + kk];
-            if (fp16_mode) {
-                const float w16 = (float)(half_t)wf;
+        for (int k0 = 0; k0 < k_top; k0 += KB) {
+            int pos[KB];
+            float wf[KB];
+            half8_t yv[KB];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float prod = (float)(half_t)(w16 * (float)yv[j]);
-                    acc[j] = (float)(half_t)(acc[j] + prod);
+            for (int i = 0; i < KB; i++) {
+                const bool in = k0 + i < k_top;
+                pos[i] = in ? inv[t * k_top + k0 + i] : -1;
+                wf[i] = in ? w[t * k_top + k0 + i] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < KB; i++)
+                if (pos[i] >= 0) yv[i] = reinterpret_cast<const half8_t*>(y + (int64_t)pos[i] * H)[c];
+#pragma unroll
+            for (int i = 0; i < KB; i++) {
+                if (pos[i] < 0) continue;
+                if (fp16_mode) {
+                    const float w16 = (float)(half_t)wf[i];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const float prod = (float)(half_t)(w16 * (float)yv[i][j]);
+                        acc[j] = (float)(half_t)(acc[j] + prod);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[j] += wf[i] * (float)yv[i][j];
                 }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; j++) acc[j] += wf * (float)yv[j];
             }
         }
         half8_t o;
@@ -998,7 +1013,7 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
         if (int rc = launch_gemm<1, 0>(ws.h, w2_q, w2_absmax, ws, FF, H, k, mt_rows, slots, ws.y, cus, st, rio, sp2, a2.u8, a2.table)) return rc;
     }
     if (!(flags & M355_FLAG_SKIP_COMBINE)) {
-        moe_combine_kernel<<<dim3(T), dim3(256), 0, st>>>(ws.y, ws.inv, w, H, k, (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0,
+        moe_combine_kernel<4><<<dim3(T), dim3(256), 0, st>>>(ws.y, ws.inv, w, H, k, (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0,
                                                           (half_t*)out_f16);
         M355_LAUNCH_CHECK("moe_combine_kernel");
     }
