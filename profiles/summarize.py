@@ -35,7 +35,9 @@ for leg, tr_file in traces:
       if short.startswith("_ZN4m35523router_topk_tile_kernel"):
           short = "router_topk_tile"
       short = short.replace("_ZN4m35524paged_attn_decode_kernelE", "paged_attn_decode").replace("_ZN4m35518router_topk_kernelE", "router_topk")
-      short = short.replace("_ZN4m35518moe_combine_kernelE", "moe_combine").split("PK")[0].split("EPK")[0]
+      if short.startswith("_ZN4m35518moe_combine_kernel"):
+          short = "moe_combine"
+      short = short.split("PK")[0].split("EPK")[0]
       key = (leg, short, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Workgroup_Size_X"]), int(r["LDS_Block_Size"]),
              int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]))
       groups[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
