@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 
 #include "m355.h"
 
@@ -37,6 +38,23 @@ inline int hip_status(hipError_t e, const char* what) {
         hipError_t e__ = hipGetLastError();                          \
         if (e__ != hipSuccess) return m355::hip_status(e__, what);   \
     } while (0)
+
+// Per-device set-up (kernel attributes and the like) that must run once on every device the library is used on.
+// Host threads may call the library concurrently: the flags are read and written under a mutex.  A device index
+// beyond the table runs the set-up on every call instead of sharing another device's flag.
+struct PerDeviceOnce {
+    std::mutex mu;
+    bool done[64] = {false};
+    template <typename F>
+    int run(int dev, F setup) {
+        std::lock_guard<std::mutex> lock(mu);
+        const bool tracked = dev >= 0 && dev < 64;
+        if (tracked && done[dev]) return 0;
+        if (int rc = setup()) return rc;
+        if (tracked) done[dev] = true;
+        return 0;
+    }
+};
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 

@@ -165,17 +165,14 @@ __global__ __launch_bounds__(DT_THREADS) void dense_tile_kernel(const half_t* __
 }
 
 static int dense_tile_device_setup_once(int dev) {
-    static bool done[64] = {false};
-    if (!done[dev & 63]) {
+    static PerDeviceOnce once;
+    return once.run(dev, [] {
         if (int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_tile_kernel<8>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, dt_lds(8)), "hipFuncSetAttribute"))
             return rc;
-        if (int rc = hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_tile_kernel<4>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, dt_lds(4)), "hipFuncSetAttribute"))
-            return rc;
-        done[dev & 63] = true;
-    }
-    return 0;
+        return hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_tile_kernel<4>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, dt_lds(4)), "hipFuncSetAttribute");
+    });
 }
 
 // Shapes were checked by the caller (K % 64 == 0, N % 16 == 0, 16-byte aligned x and w, 8-byte aligned bias/resid/out).

@@ -812,38 +812,32 @@ static int allow_big_lds(Kern kern) {
                       "hipFuncSetAttribute");
 }
 
-// Once per device: raise the dynamic-LDS limit of the GEMM kernels and read the CU count.
+// Once per device: raise the dynamic-LDS limit of the GEMM kernels; the CU count is read on every call (a cached
+// attribute query).
 static int device_setup(int dev, int* cus) {
-    static bool done[64] = {false};
-    static int ncu[64] = {0};
-    const int d = dev & 63;
-    if (!done[d]) {
-        if (int rc = allow_big_lds(&moe_gemm_kernel<0>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_kernel<1>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1, 0>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2, 0>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1, 1>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2, 1>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1, 2>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2, 2>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 1, 0>)) return rc;
-        if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 2, 0>)) return rc;
-        int v = 0;
-        if (int rc = hip_status(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute")) return rc;
-        ncu[d] = v > 0 ? v : 256;
-        done[d] = true;
-    }
-    *cus = ncu[d];
+    static PerDeviceOnce once;
+    if (int rc = once.run(dev, [] {
+            if (int rc = allow_big_lds(&moe_gemm_kernel<0>)) return rc;
+            if (int rc = allow_big_lds(&moe_gemm_kernel<1>)) return rc;
+            if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1, 0>)) return rc;
+            if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2, 0>)) return rc;
+            if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1, 1>)) return rc;
+            if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2, 1>)) return rc;
+            if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1, 2>)) return rc;
+            if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2, 2>)) return rc;
+            if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 1, 0>)) return rc;
+            return allow_big_lds(&moe_gemm_stream_kernel<1, 2, 0>);
+        }))
+        return rc;
+    int v = 0;
+    if (int rc = hip_status(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute")) return rc;
+    *cus = v > 0 ? v : 256;
     return 0;
 }
 
 static int tile_gemm_device_setup_once(int dev) {
-    static bool done[64] = {false};
-    if (!done[dev & 63]) {
-        if (int rc = tile_gemm_device_setup()) return rc;
-        done[dev & 63] = true;
-    }
-    return 0;
+    static PerDeviceOnce once;
+    return once.run(dev, [] { return tile_gemm_device_setup(); });
 }
 
 // mean (token, k) pairs per local expert from which the tile kernel takes over
