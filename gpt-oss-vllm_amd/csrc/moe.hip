@@ -478,16 +478,24 @@ __device__ __forceinline__ void build_lutp(uint32_t* lut, unsigned char* park, i
     lds_barrier();   // park is free again: everyone is done reading the codes
 }
 
-template <int MODE, int PAIRS, int INLINE>   // INLINE 0: routing lists from the workspace, 1: pairs bucketed here, 2: router too
-__global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
+// INLINE 0: routing lists from the workspace, 1: pairs bucketed here, 2: router too.  KP: K-parts per row-tile pair (the
+// waves that share an item's rows; each holds 48 / KP blocks of the item in registers).  NT: 16-token sets per token tile
+// (a tile of 16 NT tokens shares one pass over the weights; NT = 2 needs the shorter K-parts of KP = 8 to keep both
+// sets' activations in registers).
+template <int MODE, int PAIRS, int INLINE, int KP = MOE_KPARTS, int NT = 1>
+__global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
     const half_t* __restrict__ xin, const uint8_t* __restrict__ wq, const float* __restrict__ wam,
     const int32_t* __restrict__ n_tiles, const int32_t* __restrict__ tile_expert, const int32_t* __restrict__ tile_m0,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ sorted, int K, int R, int k_top, int mt_rows,
     half_t* __restrict__ outp, int table_len, RouteIO rio, StageParams sp, const uint8_t* __restrict__ wam8,
     const float* __restrict__ wtab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int THREADS = PAIRS * 256;
-    constexpr int RED_ALL = 2 * PAIRS * (MOE_KPARTS - 1) * 64 * 8 * 4;   // both reduction buffers
+    constexpr int THREADS = PAIRS * KP * 64;
+    constexpr int CH = MOE_KPARTS * MOE_CHUNK / KP;                   // blocks per wave and item
+    static_assert(CH == 12 || CH == 6, "the item body is written for 12 or 6 blocks per wave");
+    static_assert(INLINE == 0 || (KP == MOE_KPARTS && NT == 1), "inline routing is built for the 8-wave, 16-token form");
+    constexpr int RED1 = PAIRS * (KP - 1) * 64 * 8 * NT * 4;          // one reduction buffer
+    constexpr int RED_ALL = 2 * RED1;                                 // both
     uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
     unsigned char* red = smem + LUTP_BYTES;
     InlineTables* rt = reinterpret_cast<InlineTables*>(red + RED_ALL);
@@ -503,9 +511,9 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
             float* wl = lg + Tn * rio.r_E;
             int32_t* il = reinterpret_cast<int32_t*>(wl + rio.P);
             for (int t = 0; t < Tn; t++)
-                router_logits_wg<PAIRS * 4>(rio.r_x + (int64_t)t * rio.r_H, rio.r_wr, rio.r_br, rio.r_H, rio.r_E, lg + t * rio.r_E, nullptr);
+                router_logits_wg<PAIRS * KP>(rio.r_x + (int64_t)t * rio.r_H, rio.r_wr, rio.r_br, rio.r_H, rio.r_E, lg + t * rio.r_E, nullptr);
             __syncthreads();
-            for (int t = threadIdx.x >> 6; t < Tn; t += PAIRS * 4) topk_softmax_wave(lg + t * rio.r_E, rio.r_E, rio.r_k, il + t * rio.r_k, wl + t * rio.r_k);
+            for (int t = threadIdx.x >> 6; t < Tn; t += PAIRS * KP) topk_softmax_wave(lg + t * rio.r_E, rio.r_E, rio.r_k, il + t * rio.r_k, wl + t * rio.r_k);
             __syncthreads();
             if ((int)threadIdx.x < rio.P) {
                 my_e = il[threadIdx.x] - rio.e_first;
@@ -530,11 +538,6 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
 #define M355_TILE_M0(TT) (INLINE ? __builtin_amdgcn_readfirstlane(rt->tile_m0[(TT)]) : tile_m0[(TT)])
 #define M355_OFFSET(E) (INLINE ? __builtin_amdgcn_readfirstlane(rt->off[(E)]) : offsets[(E)])
 #define M355_PAIR_AT(POS) (INLINE ? rt->tok[(POS)] : sorted[(POS)])
-    constexpr int RED1 = PAIRS * (MOE_KPARTS - 1) * 64 * 8 * 4;   // one reduction buffer
-#ifndef M355_FS
-#define M355_FS 0
-#endif
-    constexpr int FS = M355_FS;   // 1: two fragment sets, pipelined steps
     const int NB = K / 64, NP = R / 32;
     const int NPG = (NP + PAIRS - 1) / PAIRS;
     // work item = (token tile of one expert, group of PAIRS row-tile pairs); a workgroup takes a contiguous range
@@ -546,23 +549,23 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pl = wave >> 2, q = wave & 3;
-    const int bq0 = q * NB / MOE_KPARTS, bq1 = (q + 1) * NB / MOE_KPARTS;   // this wave's blocks: 0..MOE_CHUNK of them
+    const int pl = wave / KP, q = wave % KP;
+    const int bq0 = q * NB / KP, bq1 = (q + 1) * NB / KP;   // this wave's blocks: 0..CH of them
     const int blast = max(bq1 - 1, bq0);   // block that out-of-part slots re-read (their scale is zero)
     const int n = lane & 15, g = lane >> 4;
     const size_t wq_expert = (size_t)R * K / 2, am_expert = (size_t)R * NB;
 
     // Register ring: W[i] holds block i of the current item until its table lookups are issued, then takes the
-    // same block of the NEXT item straight away, so one item's worth of HBM reads (12 KiB per wave) is always in
+    // same block of the NEXT item straight away, so one item's worth of HBM reads (CH KiB per wave) is always in
     // flight behind the compute.  A load is one instruction: wave-uniform base (SGPR pair, set once per item) plus a
     // per-lane byte offset that never changes (voff[i]: lane * 16 + 1 KiB per block; slots past the end of the
     // wave's K-part re-read its last block and carry a zero scale).
-    u32x4_t W[MOE_CHUNK];
+    u32x4_t W[CH];
     float4_t sA, sB, sAn, sBn;
     const unsigned char* wbase_next;
-    uint32_t voff[MOE_CHUNK];
+    uint32_t voff[CH];
 #pragma unroll
-    for (int i = 0; i < MOE_CHUNK; i++) voff[i] = (uint32_t)lane * 16u + (uint32_t)(min(bq0 + i, blast) - bq0) * 1024u;
+    for (int i = 0; i < CH; i++) voff[i] = (uint32_t)lane * 16u + (uint32_t)(min(bq0 + i, blast) - bq0) * 1024u;
 
     // aim the ring loads at item IT and request its absmax: lane (n, g) gets rows 4g..4g+3 of both tiles at block
     // bq0 + n.  The absmax is either fp32 (wam) or, as the checkpoint stores it, one code byte per block (wam8, same
@@ -611,41 +614,43 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
     if (wam8) M355_CODES_OF(it0)
     M355_POINT_AT(it0)
 #pragma unroll
-    for (int i = 0; i < MOE_CHUNK; i++) M355_LOAD(i)
+    for (int i = 0; i < CH; i++) M355_LOAD(i)
     sA = sAn;
     sB = sBn;
 
     build_lutp(lut, red, tid, THREADS);   // (while the first weights are on their way)
     const uint32_t lbase = lutp_lane_base(smem, lane);
 
-    // Every wave runs MOE_CHUNK blocks per item without branches.  Per block: M355_FETCH (16 table lookups = four A
-    // fragments, then the ring load that refills the block's registers), M355_MFMA (four MFMAs against the
-    // register-resident B fragments), M355_SCALE (absmax FMAs on the 16x16 partial products).  The compiler
+    // Every wave runs CH blocks per item without branches.  Per block: M355_FETCH (16 table lookups = four A
+    // fragments, then the ring load that refills the block's registers), M355_MFMA (four MFMAs per token set against
+    // the register-resident B fragments), M355_SCALE (absmax FMAs on the 16x16 partial products).  The compiler
     // interleaves neighbouring blocks.
 #define M355_FETCH(I, LOAD)                                                                                 \
     {                                                                                                       \
-        fa[I & FS][0] = lut4p(lbase, W[I][0]);                                                              \
-        fa[I & FS][2] = lut4p(lbase, W[I][2]);                                                              \
-        fa[I & FS][1] = lut4p(lbase, W[I][1]);                                                              \
-        fa[I & FS][3] = lut4p(lbase, W[I][3]);                                                              \
+        fa[0] = lut4p(lbase, W[I][0]);                                                                      \
+        fa[2] = lut4p(lbase, W[I][2]);                                                                      \
+        fa[1] = lut4p(lbase, W[I][1]);                                                                      \
+        fa[3] = lut4p(lbase, W[I][3]);                                                                      \
         LOAD(I)                                                                                             \
     }
 #define M355_MFMA(I)                                                                                        \
-    {                                                                                                       \
+    _Pragma("unroll") for (int s_ = 0; s_ < NT; s_++) {                                                     \
         const float4_t z = {0.f, 0.f, 0.f, 0.f};                                                            \
-        pa[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][0], xb[I][0], z, 0, 0, 0);           \
-        pb[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][2], xb[I][0], z, 0, 0, 0);           \
-        pa[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][1], xb[I][1], pa[I & FS], 0, 0, 0);  \
-        pb[I & FS] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[I & FS][3], xb[I][1], pb[I & FS], 0, 0, 0);  \
+        pa[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], xb[s_][I][0], z, 0, 0, 0);                   \
+        pb[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[2], xb[s_][I][0], z, 0, 0, 0);                   \
+        pa[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], xb[s_][I][1], pa[s_], 0, 0, 0);              \
+        pb[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[3], xb[s_][I][1], pb[s_], 0, 0, 0);              \
     }
     // element 0 of each tile goes through instructions the compiler knows (so it places the MFMA-result wait
     // states); the other elements follow as single v_fmac_f32_dpp instructions that depend on element 0's result
 #define M355_SCALE(I)                                                                                       \
-    accA[0] += row_bcast<I>(sA[0]) * pa[I & FS][0];                                                          \
-    accB[0] += row_bcast<I>(sB[0]) * pb[I & FS][0];                                                          \
-    _Pragma("unroll") for (int r = 1; r < 4; r++) {                                                         \
-        accA[r] = fmac_row_bcast_after<I>(accA[r], sA[r], pa[I & FS][r], accA[0]);                           \
-        accB[r] = fmac_row_bcast_after<I>(accB[r], sB[r], pb[I & FS][r], accB[0]);                           \
+    _Pragma("unroll") for (int s_ = 0; s_ < NT; s_++) {                                                     \
+        accA[s_][0] += row_bcast<I>(sA[0]) * pa[s_][0];                                                     \
+        accB[s_][0] += row_bcast<I>(sB[0]) * pb[s_][0];                                                     \
+        _Pragma("unroll") for (int r = 1; r < 4; r++) {                                                     \
+            accA[s_][r] = fmac_row_bcast_after<I>(accA[s_][r], sA[r], pa[s_][r], accA[s_][0]);              \
+            accB[s_][r] = fmac_row_bcast_after<I>(accB[s_][r], sB[r], pb[s_][r], accB[s_][0]);              \
+        }                                                                                                   \
     }
 #ifdef M355_EXP_NOCOMPUTE   /* experiment: keep the loads, drop table lookups and MFMAs */
 #undef M355_FETCH
@@ -653,23 +658,9 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
 #undef M355_SCALE
 #define M355_FETCH(I, LOAD) asm volatile("" ::"v"(W[I])); LOAD(I)
 #define M355_MFMA(I)
-#define M355_SCALE(I) accA[0] += sA[0]; accB[0] += sB[0];
+#define M355_SCALE(I) accA[0][0] += sA[0]; accB[0][0] += sB[0];
 #endif
 #define M355_BLOCK(I, LOAD) M355_FETCH(I, LOAD) M355_MFMA(I) M355_SCALE(I)
-    // pipelined form: lookups of block I+1, MFMAs of block I, scaling of block I-1 in one step, so the LDS and MFMA
-    // latencies of one block sit under the vector work of its neighbours
-#ifdef M355_GROUPS   /* per step: 4 x { 1 MFMA, 4 VALU, 4 LDS reads, 3 VALU } */
-#define M355_PIPE_HINT                                                                                      \
-    _Pragma("unroll") for (int h_ = 0; h_ < 4; h_++) {                                                      \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                  \
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                                  \
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                  \
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                  \
-    }
-#else
-#define M355_PIPE_HINT
-#endif
-#define M355_STEP(I, LOAD) M355_FETCH(I + 1, LOAD) M355_MFMA(I) M355_SCALE(I - 1) M355_PIPE_HINT
 
     // One work item.  LOAD is M355_LOAD while another item follows in this workgroup's range (the ring then refills
     // with it) and M355_NO_LOAD for the last one.
@@ -684,31 +675,34 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
         const int p = pg * PAIRS + pl;                                                                      \
         const bool live = p < NP;                                                                           \
         if (tt != staged_tile) {                                                                            \
-            /* this lane's B fragments of the whole K-part: token row n (clamped), columns 64b + 16g .. + 15 */ \
-            /* of each block, from global memory into registers, where they stay until the token tile changes */ \
-            const int pos = pos0 + min(n, mt - 1);                                                          \
-            const int64_t src_row = (MODE == 0) ? (int64_t)(M355_PAIR_AT(pos) / k_top) : (int64_t)pos;      \
-            const u32x4_t* src = reinterpret_cast<const u32x4_t*>(xin + src_row * K) + 2 * g;               \
-            _Pragma("unroll") for (int i = 0; i < MOE_CHUNK; i++) {                                         \
-                const int bb = min(bq0 + i, blast);                                                         \
-                xb[i][0] = __builtin_bit_cast(half8_t, src[8 * bb]);                                        \
-                xb[i][1] = __builtin_bit_cast(half8_t, src[8 * bb + 1]);                                    \
+            /* this lane's B fragments of the whole K-part: token rows n, n + 16, .. (clamped), columns */  \
+            /* 64b + 16g .. + 15 of each block, from global memory into registers, where they stay until */ \
+            /* the token tile changes */                                                                    \
+            _Pragma("unroll") for (int s_ = 0; s_ < NT; s_++) {                                             \
+                const int pos = pos0 + min(n + 16 * s_, mt - 1);                                            \
+                const int64_t src_row = (MODE == 0) ? (int64_t)(M355_PAIR_AT(pos) / k_top) : (int64_t)pos;  \
+                const u32x4_t* src = reinterpret_cast<const u32x4_t*>(xin + src_row * K) + 2 * g;           \
+                _Pragma("unroll") for (int i = 0; i < CH; i++) {                                            \
+                    const int bb = min(bq0 + i, blast);                                                     \
+                    xb[s_][i][0] = __builtin_bit_cast(half8_t, src[8 * bb]);                                \
+                    xb[s_][i][1] = __builtin_bit_cast(half8_t, src[8 * bb + 1]);                            \
+                }                                                                                           \
             }                                                                                               \
             staged_tile = tt;                                                                               \
         }                                                                                                   \
         if (MORE) M355_POINT_AT(it + 1)                                                                     \
-        float4_t accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};                                  \
-        half8_t fa[FS + 1][4];                                                                              \
-        float4_t pa[FS + 1], pb[FS + 1];                                                                    \
-        if (FS) {                                                                                           \
-            M355_FETCH(0, LOAD) M355_FETCH(1, LOAD) M355_MFMA(0)                                            \
-            M355_STEP(1, LOAD) M355_STEP(2, LOAD) M355_STEP(3, LOAD) M355_STEP(4, LOAD) M355_STEP(5, LOAD)  \
-            M355_STEP(6, LOAD) M355_STEP(7, LOAD) M355_STEP(8, LOAD) M355_STEP(9, LOAD) M355_STEP(10, LOAD) \
-            M355_MFMA(11) M355_SCALE(10) M355_SCALE(11)                                                     \
-        } else {                                                                                            \
-            M355_BLOCK(0, LOAD) M355_BLOCK(1, LOAD) M355_BLOCK(2, LOAD) M355_BLOCK(3, LOAD)                 \
-            M355_BLOCK(4, LOAD) M355_BLOCK(5, LOAD) M355_BLOCK(6, LOAD) M355_BLOCK(7, LOAD)                 \
-            M355_BLOCK(8, LOAD) M355_BLOCK(9, LOAD) M355_BLOCK(10, LOAD) M355_BLOCK(11, LOAD)               \
+        float4_t accA[NT], accB[NT];                                                                        \
+        _Pragma("unroll") for (int s_ = 0; s_ < NT; s_++) {                                                 \
+            accA[s_] = float4_t{0.f, 0.f, 0.f, 0.f};                                                        \
+            accB[s_] = float4_t{0.f, 0.f, 0.f, 0.f};                                                        \
+        }                                                                                                   \
+        half8_t fa[4];                                                                                      \
+        float4_t pa[NT], pb[NT];                                                                            \
+        M355_BLOCK(0, LOAD) M355_BLOCK(1, LOAD) M355_BLOCK(2, LOAD) M355_BLOCK(3, LOAD)                     \
+        M355_BLOCK(4, LOAD) M355_BLOCK(5, LOAD)                                                             \
+        if constexpr (CH > 6) {                                                                             \
+            M355_BLOCK(6, LOAD) M355_BLOCK(7, LOAD) M355_BLOCK(8, LOAD) M355_BLOCK(9, LOAD)                 \
+            M355_BLOCK(10, LOAD) M355_BLOCK(11, LOAD)                                                       \
         }                                                                                                   \
         sA = sAn;                                                                                           \
         sB = sBn;                                                                                           \
@@ -716,24 +710,29 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
         float4_t* rbuf = reinterpret_cast<float4_t*>(red + (round & 1) * RED1);                             \
         round++;                                                                                            \
         if (q > 0) {                                                                                        \
-            float4_t* dst = rbuf + ((size_t)(pl * (MOE_KPARTS - 1) + (q - 1)) * 64 + lane) * 2;             \
-            dst[0] = accA;                                                                                  \
-            dst[1] = accB;                                                                                  \
+            float4_t* dst = rbuf + ((size_t)(pl * (KP - 1) + (q - 1)) * 64 + lane) * 2 * NT;                \
+            _Pragma("unroll") for (int s_ = 0; s_ < NT; s_++) {                                             \
+                dst[2 * s_] = accA[s_];                                                                     \
+                dst[2 * s_ + 1] = accB[s_];                                                                 \
+            }                                                                                               \
         }                                                                                                   \
         lds_barrier();                                                                                      \
         if (q == 0 && live) {                                                                               \
-            _Pragma("unroll") for (int qq = 0; qq < MOE_KPARTS - 1; qq++) {                                 \
-                const float4_t* src = rbuf + ((size_t)(pl * (MOE_KPARTS - 1) + qq) * 64 + lane) * 2;        \
-                accA += src[0];                                                                             \
-                accB += src[1];                                                                             \
+            _Pragma("unroll") for (int qq = 0; qq < KP - 1; qq++) {                                         \
+                const float4_t* src = rbuf + ((size_t)(pl * (KP - 1) + qq) * 64 + lane) * 2 * NT;           \
+                _Pragma("unroll") for (int s_ = 0; s_ < NT; s_++) {                                         \
+                    accA[s_] += src[2 * s_];                                                                \
+                    accB[s_] += src[2 * s_ + 1];                                                            \
+                }                                                                                           \
             }                                                                                               \
-            if (n < mt) gemm_epilogue<MODE>(accA, accB, outp, pos0 + n, R, NP, p, g, e, sp);                \
+            _Pragma("unroll") for (int s_ = 0; s_ < NT; s_++)                                               \
+                if (n + 16 * s_ < mt) gemm_epilogue<MODE>(accA[s_], accB[s_], outp, pos0 + n + 16 * s_, R, NP, p, g, e, sp); \
         }                                                                                                   \
     }
 
     int staged_tile = -1;
     int round = 0;
-    half8_t xb[MOE_CHUNK][2];
+    half8_t xb[NT][CH][2];
     for (int itx = it0; itx < it1 - 1; itx++) M355_ITEM(itx, M355_LOAD, true)
     M355_ITEM(it1 - 1, M355_NO_LOAD, false)
 #undef M355_ITEM
@@ -742,8 +741,6 @@ __global__ __launch_bounds__(PAIRS * 256) void moe_gemm_stream_kernel(
 #undef M355_OFFSET
 #undef M355_PAIR_AT
 #undef M355_BLOCK
-#undef M355_STEP
-#undef M355_PIPE_HINT
 #undef M355_SCALE
 #undef M355_MFMA
 #undef M355_FETCH
@@ -806,6 +803,12 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(const half_t* __restri
 static int gemm_lds_bytes(int K, int mt_rows) { return LUT_BYTES + RED_BYTES + mt_rows * (K * 2 + XS_PAD); }
 
 
+// The streaming kernel's form for 17 .. 32 tokens per expert and up: token tiles of 32 (two 16-token sets share one pass
+// over the weights), one row-tile pair per item, 8 K-parts of 6 blocks per wave.
+constexpr int WIDE_KP = 8;
+constexpr int WIDE_MT = 32;
+constexpr int WIDE_MIN_MEAN_PAIRS = 16;   // mean (token, k) pairs per local expert from which the 32-token tiles pay
+
 template <typename Kern>
 static int allow_big_lds(Kern kern) {
     return hip_status(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
@@ -826,7 +829,9 @@ static int device_setup(int dev, int* cus) {
             if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1, 2>)) return rc;
             if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 2, 2>)) return rc;
             if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 1, 0>)) return rc;
-            return allow_big_lds(&moe_gemm_stream_kernel<1, 2, 0>);
+            if (int rc = allow_big_lds(&moe_gemm_stream_kernel<1, 2, 0>)) return rc;
+            if (int rc = allow_big_lds(&moe_gemm_stream_kernel<0, 1, 0, WIDE_KP, 2>)) return rc;
+            return allow_big_lds(&moe_gemm_stream_kernel<1, 1, 0, WIDE_KP, 2>);
         }))
         return rc;
     int v = 0;
@@ -841,10 +846,10 @@ static int tile_gemm_device_setup_once(int dev) {
 }
 
 // mean (token, k) pairs per local expert from which the tile kernel takes over
-constexpr int TILE_MIN_MEAN_PAIRS = 40;   // measured crossover on gpt-oss-20b shapes (32 experts: about 320 tokens)
+constexpr int TILE_MIN_MEAN_PAIRS = 68;   // measured crossover against the 32-token streaming form on gpt-oss-20b shapes (32 experts: about 540 tokens)
 
-static int stream_lds_bytes(int pairs, int inline_route) {   // (activations live in registers)
-    return LUTP_BYTES + 2 * pairs * (MOE_KPARTS - 1) * 64 * 8 * 4 + (inline_route ? (int)align_up(sizeof(InlineTables), 16) : 0);
+static int stream_lds_bytes(int pairs, int inline_route, int kparts = MOE_KPARTS, int token_sets = 1) {   // (activations live in registers)
+    return LUTP_BYTES + 2 * pairs * (kparts - 1) * 64 * 8 * token_sets * 4 + (inline_route ? (int)align_up(sizeof(InlineTables), 16) : 0);
 }
 
 // A gate_up launch can bucket the pairs itself when a pair per thread and two experts per lane cover them.
@@ -864,6 +869,17 @@ static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, c
         const int max_tiles = (ws.max_pairs / k_top <= MOE_MAX_MT) ? slots : slots + ws.max_pairs / mt_rows;
         const int items2 = max_tiles * ((NP + 1) / 2);
         const int table_len = ws.max_pairs + slots < 64 ? ws.max_pairs + slots : 64;   // the table holds P + E_local entries
+        if constexpr (INLINE == 0) {
+            if (mt_rows == WIDE_MT) {   // 32-token tiles: one pair per item, 8 K-parts of 6 blocks, two token sets
+                const int lds = stream_lds_bytes(1, 0, WIDE_KP, 2);
+                const int items1 = max_tiles * NP;
+                const int grid = items1 < cus ? items1 : cus;
+                moe_gemm_stream_kernel<MODE, 1, 0, WIDE_KP, 2><<<dim3(grid), dim3(WIDE_KP * 64), lds, st>>>(
+                    xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio, sp, wam8, wtab);
+                M355_LAUNCH_CHECK("moe_gemm_stream_kernel");
+                return 0;
+            }
+        }
         if (2 * items2 >= cus) {   // 8-wave workgroups unless even those would leave most CUs idle
             const int lds = stream_lds_bytes(2, INLINE);
             const int grid = items2 < cus ? items2 : cus;
@@ -958,17 +974,22 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
     bool tiled = T > MOE_MAX_MT && (int64_t)P >= (int64_t)TILE_MIN_MEAN_PAIRS * E_local;
     if (flags & M355_FLAG_FORCE_TILE) tiled = true;
     if (flags & M355_FLAG_FORCE_STREAM) tiled = false;
-    const int mt_rows = tiled ? TILE_ROWS : (T < MOE_MAX_MT ? T : MOE_MAX_MT);
+    // between the two: from WIDE_MIN_MEAN_PAIRS pairs per expert the streaming kernel takes token tiles of 32
+    bool wide = !tiled && T > MOE_MAX_MT && H / 64 <= MOE_KPARTS * MOE_CHUNK && FF / 64 <= MOE_KPARTS * MOE_CHUNK;
+    if (wide && !(flags & M355_FLAG_STREAM_WIDE))
+        wide = !(flags & M355_FLAG_FORCE_STREAM) && (int64_t)P >= (int64_t)WIDE_MIN_MEAN_PAIRS * E_local;
+    const int mt_rows = tiled ? TILE_ROWS : wide ? WIDE_MT : (T < MOE_MAX_MT ? T : MOE_MAX_MT);
     const int slots = P < E_local ? P : E_local;
 
     int dev = 0, cus = 0;
     if (int rc = hip_status(hipGetDevice(&dev), "hipGetDevice")) return rc;
     if (int rc = device_setup(dev, &cus)) return rc;
-    if (!tiled && (gemm_lds_bytes(H, mt_rows) > 160 * 1024 || gemm_lds_bytes(FF, mt_rows) > 160 * 1024))
+    const bool general_kernel = !tiled && (H / 64 > MOE_KPARTS * MOE_CHUNK || FF / 64 > MOE_KPARTS * MOE_CHUNK);   // (stages activations in LDS)
+    if (general_kernel && (gemm_lds_bytes(H, mt_rows) > 160 * 1024 || gemm_lds_bytes(FF, mt_rows) > 160 * 1024))
         return fail(-2, "m355_moe_nf4_forward: H or FF too large for the LDS activation tile");
 
     // gate_up buckets the pairs itself when it can; the routing kernel runs when it cannot, or when gate_up is skipped
-    const bool inline_route = !tiled && can_route_inline(P, E_local, H) && !(flags & M355_FLAG_SKIP_GATE_UP);
+    const bool inline_route = !tiled && !wide && can_route_inline(P, E_local, H) && !(flags & M355_FLAG_SKIP_GATE_UP);
     // The router: inside the gate_up launch for a handful of tokens (saves a launch and its wait), else its own launch
     const bool fuse_router = router.wr && inline_route && T <= FUSE_ROUTER_MAX_T && router.E_global <= FUSE_ROUTER_MAX_E &&
                              !(flags & M355_FLAG_SKIP_ROUTE);

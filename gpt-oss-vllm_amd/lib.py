@@ -18,7 +18,7 @@ ACT_SILU_CONCAT = 0
 ACT_SWIGLU_OAI = 1
 FLAG_FP16_COMBINE = 1
 FLAG_SKIP_ROUTE, FLAG_SKIP_GATE_UP, FLAG_SKIP_DOWN, FLAG_SKIP_COMBINE = 0x100, 0x200, 0x400, 0x800
-FLAG_FORCE_STREAM, FLAG_FORCE_TILE = 0x1000, 0x2000
+FLAG_FORCE_STREAM, FLAG_FORCE_TILE, FLAG_STREAM_WIDE = 0x1000, 0x2000, 0x4000
 
 # every symbol include/m355.h declares
 EXPORTS = (
@@ -174,7 +174,8 @@ def moe_workspace_bytes(T: int, k: int, H: int, FF: int, E_local: int) -> int:
     return int(load().m355_moe_workspace_bytes(T, k, H, FF, E_local))
 
 
-TILE_MIN_MEAN_PAIRS = 40   # the library's own crossover between its two MoE GEMM kernels (csrc/moe.hip)
+TILE_MIN_MEAN_PAIRS = 68   # the library's own crossover between its two MoE GEMM kernels (csrc/moe.hip)
+WIDE_MIN_MEAN_PAIRS = 16   # ... and, within the streaming kernel, between token tiles of 16 and of 32
 
 
 def kernel_choice_flags(tokens: int, top_k: int, global_experts: int) -> int:
@@ -182,7 +183,10 @@ def kernel_choice_flags(tokens: int, top_k: int, global_experts: int) -> int:
     expert is local.  A rank that holds a shard sees the tokens of all ranks but only its share of the pairs: there
     the caller, who knows the global expert count, fixes the choice with this flag."""
     many = tokens > 16 and tokens * top_k >= TILE_MIN_MEAN_PAIRS * global_experts
-    return FLAG_FORCE_TILE if many else FLAG_FORCE_STREAM
+    if many:
+        return FLAG_FORCE_TILE
+    wide = tokens > 16 and tokens * top_k >= WIDE_MIN_MEAN_PAIRS * global_experts
+    return FLAG_FORCE_STREAM | (FLAG_STREAM_WIDE if wide else 0)
 
 
 def moe_nf4_forward(x, ids, w, w13_q, w13_absmax, w2_q, w2_absmax, *, E_local: int, e_first: int, H: int, FF: int,

@@ -46,6 +46,11 @@ typedef void* m355_stream_t; /* a hipStream_t (NULL = the default stream) */
    (token tiles of 256, weights dequantised once per tile).  Both compute the same layer. */
 #define M355_FLAG_FORCE_STREAM 0x1000
 #define M355_FLAG_FORCE_TILE 0x2000
+/* With FORCE_STREAM: token tiles of 32 instead of 16 (two 16-token sets share one pass over an expert's weights), the
+   form the library itself picks from 16 pairs per local expert on.  A rank that holds a shard of the experts sees the
+   token slots of all ranks but only its share of the pairs, so there the caller, who knows the global expert count,
+   makes the choice. */
+#define M355_FLAG_STREAM_WIDE 0x4000
 
 M355_API int m355_version(void);
 M355_API const char* m355_last_error(void);

@@ -133,7 +133,8 @@ def test_router_cast_helper():
 def test_kernel_choice_for_expert_shards():
     """A shard sees every rank's token slots but only its share of the pairs: the choice follows the global count."""
     from gpt_oss_vllm_amd import lib
-    assert lib.kernel_choice_flags(256, 4, 32) == lib.FLAG_FORCE_STREAM      # 8 ranks x 32 tokens: 32 pairs per expert
+    assert lib.kernel_choice_flags(256, 4, 32) == lib.FLAG_FORCE_STREAM | lib.FLAG_STREAM_WIDE   # 8 ranks x 32 tokens: 32 pairs per expert, token tiles of 32
+    assert lib.kernel_choice_flags(64, 4, 32) == lib.FLAG_FORCE_STREAM       # 2 ranks x 32 tokens: 8 pairs per expert, token tiles of 16
     assert lib.kernel_choice_flags(8192, 4, 32) == lib.FLAG_FORCE_TILE
     assert lib.kernel_choice_flags(8192, 4, 128) == lib.FLAG_FORCE_TILE
     assert lib.kernel_choice_flags(16, 32, 4) == lib.FLAG_FORCE_STREAM        # a token tile of <= 16 never takes the tile kernel

@@ -430,9 +430,12 @@ def test_moe_tile_kernel_vs_oracle_and_stream_kernel(T, E, k, H, FF, act, ref, m
     F = m355.FLAG_FP16_COMBINE
     tile = m355.moe_nf4_forward(xd, ids, w, *tl, flags=F | m355.FLAG_FORCE_TILE, **kw)
     stream = m355.moe_nf4_forward(xd, ids, w, *tl, flags=F | m355.FLAG_FORCE_STREAM, **kw)
+    # the streaming kernel's form with token tiles of 32 (ragged last tiles, experts with 0 .. several tiles)
+    wide = m355.moe_nf4_forward(xd, ids, w, *tl, flags=F | m355.FLAG_FORCE_STREAM | m355.FLAG_STREAM_WIDE, **kw)
     torch.cuda.synchronize()
-    assert torch.isfinite(tile.float()).all()
+    assert torch.isfinite(tile.float()).all() and torch.isfinite(wide.float()).all()
     _close(tile.cpu().numpy(), stream.cpu().numpy())
+    _close(wide.cpu().numpy(), stream.cpu().numpy())
     ids_h, w_h = ids.cpu().numpy(), w.cpu().numpy()
     if act == "oai":
         w13 = np.stack([ref.nf4_dequant(layer["w13_q"][e], 2 * FF * H, layer["w13_absmax"][e]).reshape(2 * FF, H) for e in range(E)])
@@ -444,9 +447,11 @@ def test_moe_tile_kernel_vs_oracle_and_stream_kernel(T, E, k, H, FF, act, ref, m
         b13_il[:, 0::2], b13_il[:, 1::2] = b13[:, :FF], b13[:, FF:]
         want = ref.moe_forward_oai(x, ids_h, w_h, w13_il, w2, b13_il, b2)
         _close(tile.cpu().numpy(), want, rtol=5e-3)
+        _close(wide.cpu().numpy(), want, rtol=5e-3)
     else:
         want = ref.moe_forward(x, ids_h, w_h, **layer, E_local=E, H=H, FF=FF)
         _close(tile.cpu().numpy(), want)
+        _close(wide.cpu().numpy(), want)
 
 
 def test_moe_tile_kernel_prefill_size(ref, m355, cuda):
