@@ -32,6 +32,19 @@ typedef __attribute__((address_space(3))) short4_t ap_lds_s4_t;
 typedef __attribute__((address_space(3))) void ap_lds_void_t;
 typedef const __attribute__((address_space(1))) void ap_glb_void_t;
 
+// Combine a value with the one lane ^ 32 holds: one v_permlane32_swap (the upper half of the first operand trades places
+// with the lower half of the second) leaves both halves' values on every lane, no LDS round trip.
+__device__ __forceinline__ float cross_half_max(float v) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, v);
+    const auto sw = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    return fmaxf(__builtin_bit_cast(float, (uint32_t)sw[0]), __builtin_bit_cast(float, (uint32_t)sw[1]));
+}
+__device__ __forceinline__ float cross_half_sum(float v) {
+    const uint32_t b = __builtin_bit_cast(uint32_t, v);
+    const auto sw = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    return __builtin_bit_cast(float, (uint32_t)sw[0]) + __builtin_bit_cast(float, (uint32_t)sw[1]);
+}
+
 __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
     const half_t* __restrict__ q, const half_t* __restrict__ k, const half_t* __restrict__ v,
     const int32_t* __restrict__ seq_starts, int Hq, int64_t q_stride, int64_t kv_stride, int64_t o_stride, float scale,
@@ -92,7 +105,8 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
 
     if (t_lo < t_hi) stage(t_lo, t_lo & 1);
     for (int t = t_lo; t < t_hi; t++) {
-        // this tile has landed (every wave's DMA), and nobody reads the other buffer any more
+        // this tile has landed (every wave's DMA), and nobody reads the other buffer any more.  (Requesting tiles two or
+        // three ahead into three or four buffers was measured: 2-3 % slower, the DMA latency is not what the loop waits for.)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (t + 1 < t_hi) stage(t + 1, (t + 1) & 1);
         const uint32_t base = (uint32_t)((t & 1) * 2 * AP_TILE_BYTES);
@@ -109,7 +123,8 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
                 x = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], x, 0, 0, 0);
             }
             // register i of lane (q, h) is key kbase + (i & 3) + 8 (i >> 2) + 4 h
-            float mx = -INFINITY;
+            // The scores stay unscaled: the maximum is taken on the raw values (the scale is positive) and the scale
+            // (in units of log2(e): exp2 below) goes into the one fused multiply-add that forms the exponent.
             // only half tiles on the diagonal or on the window's edge need the per-element test
             const bool edge = kbase + 31 > q0 || (window > 0 && kbase <= q0 + AP_QBLK - 1 - window);
             if (edge) {
@@ -117,17 +132,14 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
                 for (int i = 0; i < 16; i++) {
                     const int kabs = kbase + (i & 3) + 8 * (i >> 2) + 4 * hh;
                     const bool ok = kabs <= qabs && (window <= 0 || kabs > qabs - window);
-                    x[i] = ok ? x[i] * scale2 : -INFINITY;   // scores in units of log2(e): exp2 below
-                    mx = fmaxf(mx, x[i]);
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    x[i] *= scale2;
-                    mx = fmaxf(mx, x[i]);
+                    x[i] = ok ? x[i] : -INFINITY;
                 }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float mx = fmaxf(fmaxf(x[0], x[1]), x[2]);
+#pragma unroll
+            for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, x[i]), x[i + 1]);
+            mx = fmaxf(mx, x[15]);
+            mx = cross_half_max(mx) * scale2;
             const float m_new = fmaxf(m_run, mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;   // every key so far masked: all terms are 0
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
@@ -135,11 +147,11 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
             half8_t pf[2];
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const float p = __builtin_amdgcn_exp2f(x[i] - m_use);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], scale2, -m_use));
                 rs += p;
                 pf[i >> 3][i & 7] = (half_t)p;
             }
-            rs += __shfl_xor(rs, 32, 64);
+            rs = cross_half_sum(rs);
             l_run = l_run * alpha + rs;
             m_run = m_new;
             if (__any(alpha != 1.0f)) {   // (once the running maxima have settled nothing is rescaled)
