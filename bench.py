@@ -153,6 +153,12 @@ class DecodeStep:
         self._side_stream_pass()
         self.graph = [(False, self._capture_one(self.run_eager).replay)]
 
+    def prepare(self):
+        """For a step that is launched call by call (experts sharded: collectives between the kernels): every run of
+        kernels between two collectives becomes one list of prepared library calls (arguments checked and converted
+        once), the collectives stay ordinary torch.distributed calls."""
+        self.graph = [(True, fn) if is_coll else (False, self.lib.prepare(fn)) for is_coll, fn in self.pieces()]
+
     def step(self):
         if self.graph is not None:
             for _, fn in self.graph:
@@ -561,6 +567,8 @@ def main():
     def capture(stepper):
         if use_graph:
             stepper.capture()
+        elif sharded and not a.eager:
+            stepper.prepare()
 
     capture(main_step)
     dt = timed(main_step, a.steps, a.warmup, world)
@@ -576,6 +584,7 @@ def main():
                          + (("1 GPU: BASELINE configs[2]" if a.shape == "20b" else "1 GPU, the model shape of BASELINE configs[4]") if world == 1 else f"experts sharded over {world} GPUs (EP, all-to-all): BASELINE configs[3] shape")),
             "batch_per_gpu": a.batch_per_gpu, "global_batch": tokens, "seq_len": a.ctx,
             "parallelism": "single" if world == 1 else f"ep{world}+dp{world}", "hip_graph": use_graph,
+            "host_calls": "hip graph" if use_graph else ("plain" if a.eager or not sharded else "prepared"),
             "absmax_storage": a.absmax,
         },
     }

@@ -110,8 +110,64 @@ def _dev(t: torch.Tensor, dtype: torch.dtype, name: str) -> int:
     return t.data_ptr()
 
 
+class _StreamArg(int):
+    """The current stream's handle; its type marks the stream argument of a library call for prepare()."""
+
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _StreamArg(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
+
+
+class _Recorder:
+    """Stands in for the loaded library while prepare() runs: every call that ends in a stream argument is carried out
+    and written down as (name, C function, arguments)."""
+
+    def __init__(self, L):
+        self._L, self.calls = L, []
+
+    def __getattr__(self, name):
+        fn = getattr(self._L, name)
+
+        def call(*args):
+            if args and isinstance(args[-1], _StreamArg):
+                self.calls.append((name, fn, args[:-1]))
+            return fn(*args)
+        return call
+
+
+class Prepared:
+    """Library calls with their arguments checked and converted once.  Calling the object issues them again, in order,
+    on the stream that is current then: for loops that repeat the same calls on the same buffers without a HIP graph
+    (a step that holds collectives, or vLLM's --enforce-eager), where the per-call checks and conversions of the
+    wrappers above cost more host time than the launch itself.  The tensors must stay alive and keep their addresses:
+    the object holds on to `owner` (normally the closure that made the calls) for that."""
+
+    def __init__(self, calls, device_index, owner):
+        self._dev, self._owner = device_index, owner
+        self._calls = []
+        for name, fn, args in calls:
+            conv = tuple(a if a is None else t(a) for t, a in zip(fn.argtypes, args))
+            self._calls.append((name, fn, conv))
+
+    def __call__(self):
+        st = torch._C._cuda_getCurrentRawStream(self._dev)
+        for name, fn, args in self._calls:
+            rc = fn(*args, st)
+            if rc != 0:
+                _check(rc, name)
+
+
+def prepare(fn) -> Prepared:
+    """Run fn() once (its library calls are carried out as usual) and return a Prepared that repeats those calls."""
+    global _lib
+    real = load()
+    rec = _Recorder(real)
+    _lib = rec
+    try:
+        fn()
+    finally:
+        _lib = real
+    return Prepared(rec.calls, torch.cuda.current_device(), fn)
 
 
 def version() -> int:

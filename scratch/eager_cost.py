@@ -34,4 +34,27 @@ for name, fn in calls.items():
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"{name:24s} cpu {1e6*(t1-t0)/n:7.1f} us/call   incl. drain {1e6*(t2-t0)/n:7.1f} us/call", flush=True)
+
+import time
+for mode in ("plain", "prepared"):
+    if mode == "prepared": st.prepare()
+    for _ in range(5): st.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20): st.step()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"{mode}: step of 4 layers: host enqueue {1e6*(t1-t0)/20:.0f} us, with drain {1e6*(t2-t0)/20:.0f} us", flush=True)
+pp = st.graph
+names = ["k0","a2a","k1","a2a_back","k2"]
+for i in range(5):
+    isc, fn = pp[i]
+    for _ in range(20): fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200): fn()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    print(f"piece {i} ({'collective' if isc else 'kernels'}): host {1e6*(t1-t0)/200:.1f} us", flush=True)
 dist.destroy_process_group()

@@ -583,3 +583,28 @@ def test_attention_prefill_last_token_equals_decode(ref, m355, cuda):
                                  _to_dev(np.array([L], np.int32), cuda), max_ctx=L, scale=D ** -0.5)
     torch.cuda.synchronize()
     _close(pre[L - 1].cpu().numpy(), dec[0].cpu().numpy())
+
+
+# ------------------------------------------------------------------------------------------------
+# Prepared calls (arguments checked and converted once) repeat the wrappers' library calls exactly.
+@pytest.mark.gpu
+def test_prepared_calls_repeat_the_wrappers(ref, m355, cuda):
+    T, E, k, H = 8, 32, 4, 2880
+    x = _to_dev(ref.normal_f16(ref.stream_seed(77, 1), (T, H)), cuda)
+    wr = _to_dev(ref.normal_f16(ref.stream_seed(77, 2), (E, H), 0.02), cuda)
+    ids = torch.empty((T, k), dtype=torch.int32, device=cuda)
+    w = torch.empty((T, k), dtype=torch.float32, device=cuda)
+    logits_a = m355.router_topk(x, wr, None, k, want_logits=True)[2].clone()
+    want_ids, want_w = m355.router_topk(x, wr, None, k)
+    prepared = m355.prepare(lambda: m355.router_topk(x, wr, None, k, ids=ids, w=w))
+    ids.fill_(-1)
+    w.zero_()
+    prepared()
+    torch.cuda.synchronize()
+    assert torch.equal(ids, want_ids) and torch.equal(w, want_w)
+    assert torch.isfinite(logits_a.float()).all()
+    # a failing call inside prepare() raises as the wrapper does, and the library is back in place afterwards
+    with pytest.raises(m355.Mi355LibraryError):
+        m355.prepare(lambda: m355.router_topk(x, wr, None, 64, ids=torch.empty((T, 64), dtype=torch.int32, device=cuda),
+                                              w=torch.empty((T, 64), dtype=torch.float32, device=cuda)))
+    assert m355.router_topk(x, wr, None, k)[0].shape == (T, k)
