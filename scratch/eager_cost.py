@@ -46,6 +46,21 @@ for mode in ("plain", "prepared"):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"{mode}: step of 4 layers: host enqueue {1e6*(t1-t0)/20:.0f} us, with drain {1e6*(t2-t0)/20:.0f} us", flush=True)
+
+# the same step with the all-to-all replaced by a copy on the launch stream (one rank: same bytes), to see what the
+# collective's own stream and its event hops cost
+for lay in st.L:
+    lay["ep"].exchange = lambda recv, send: recv.copy_(send)
+st.graph = None
+st.prepare()
+for _ in range(5): st.step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20): st.step()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"prepared, same-stream copy instead of all_to_all_single: host enqueue {1e6*(t1-t0)/20:.0f} us, with drain {1e6*(t2-t0)/20:.0f} us", flush=True)
 pp = st.graph
 names = ["k0","a2a","k1","a2a_back","k2"]
 for i in range(5):
