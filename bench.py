@@ -35,6 +35,21 @@ MFMA_PEAK_TFLOPS = 2500.0    # dense fp16
 GATE_UP_FLOPS_PER_PAIR = 2 * 2 * FF * H   # one (token, expert) pair through W13
 
 
+def profiled_mfma_busy():
+    """Fraction of the launch's cycles in which the matrix cores were busy, for the tile kernel's gate_up launch, from
+    the newest committed counter profile (collected in separate rocprofv3 --pmc passes, not in this run)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            d = json.load(f)
+        return d.get("tile_gate_up_mfma_busy_frac"), os.path.basename(files[-1])
+    except (OSError, ValueError):
+        return None, None
+
+
 def profiled_traffic():
     """HBM bytes per gate_up launch from the newest committed counter profile (profiles/rNN_traffic.json, written by
     profiles/summarize.py from separate rocprofv3 --pmc passes): counters cannot be read from inside this run."""
@@ -463,6 +478,7 @@ def prefill_leg(lib, main_step, device, tokens, reps=3):
         "roofline": {"bound": "mfma", "kernel": "moe_tile_gemm_kernel<gate_up> (NF4 dequant fused into the grouped GEMM, 256-token tiles)",
                      "achieved": fl_gu / t_gu / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": fl_gu / t_gu / 1e12 / MFMA_PEAK_TFLOPS, "avg_us": t_gu * 1e6, "flops_per_launch": fl_gu,
+                     "mfma_busy_frac_counters": profiled_mfma_busy()[0], "mfma_busy_source": profiled_mfma_busy()[1],
                      "down_kernel": {"achieved": fl_gu / 2 / t_dn / 1e12, "avg_us": t_dn * 1e6,
                                      "frac": fl_gu / 2 / t_dn / 1e12 / MFMA_PEAK_TFLOPS}},
     }

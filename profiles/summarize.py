@@ -43,6 +43,7 @@ for leg, tr_file in traces:
       groups[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 
 tile_pmc = collections.defaultdict(list)
+mfma_busy = {}
 for f in glob.glob(f"{src}/pmc_tile_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         if "moe_tile" in r["Kernel_Name"]:
@@ -81,6 +82,7 @@ if tile_pmc:
             busy, act = tile_pmc.get((kern, "SQ_VALU_MFMA_BUSY_CYCLES")), tile_pmc.get((kern, "GRBM_GUI_ACTIVE"))
             if busy and act:
                 cyc = sum(act) / len(act) / 8          # the counter sums the 8 XCDs
+                mfma_busy[kern] = sum(busy) / len(busy) / (1024 * cyc)
                 out.write(f"\n{kern}: matrix cores busy {sum(busy) / len(busy) / (1024 * cyc):.3f} of the cycles of the launch "
                           f"(SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 = {cyc:.4g} cycles)).\n")
 rd = pmc.get(("gate_up", "TCC_EA0_RDREQ_sum"))
@@ -89,5 +91,8 @@ if rd:
     with open(f"profiles/{tag}_traffic.json", "w") as out:
         json.dump({"gate_up_hbm_bytes_per_launch": sum(rd) / len(rd) * 128,
                    "down_hbm_bytes_per_launch": (sum(rd_down) / len(rd_down) * 128) if rd_down else None,
-                   "source": "TCC_EA0_RDREQ_sum x 128 B, rocprofv3 --pmc pass over scratch/prof_moe.py (bs=32)"}, out, indent=1)
+                   "source": "TCC_EA0_RDREQ_sum x 128 B, rocprofv3 --pmc pass over scratch/prof_moe.py (bs=32)",
+                   "tile_gate_up_mfma_busy_frac": mfma_busy.get("gate_up"), "tile_down_mfma_busy_frac": mfma_busy.get("down"),
+                   "mfma_busy_source": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), rocprofv3 --pmc passes "
+                                       "over scratch/prof_tile.py (8192 tokens, 32 experts)"}, out, indent=1)
 print(open(f"profiles/{tag}_summary.md").read()[:3000])
