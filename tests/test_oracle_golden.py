@@ -134,3 +134,28 @@ def test_paged_attention_oracle_vs_dense_numpy(ref):
             p = np.exp(s - s.max())
             o = (p / p.sum()) @ V
             assert np.abs(out[b, h] - o).max() < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# Property test: the C restatement and its numpy twin agree bit for bit on arbitrary sizes, including the branches
+# of the reference's dequantiser that real checkpoints never take (block count that does not divide the element
+# count, a single absmax, no absmax at all).
+def test_c_oracle_equals_numpy_twin_on_random_shapes(ref):
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(1, 40), st.sampled_from([1, 2, 3, 64, 128]), st.integers(-2, 3), st.integers(0, 2 ** 31 - 1))
+    def check(blocks, blocksize_hint, extra, seed):
+        rng = np.random.default_rng(seed)
+        n = 2 * ((blocks * 64 + 1) // 2)
+        q = rng.integers(0, 256, n // 2, dtype=np.uint8)
+        if blocksize_hint in (64, 128):
+            n_abs = max(1, (n + blocksize_hint - 1) // blocksize_hint + extra)
+        else:
+            n_abs = blocksize_hint      # 1, 2 or 3 entries: scalar / odd splits
+        a = (rng.random(n_abs, dtype=np.float32) * 0.05 + 1e-3).astype(np.float32)
+        c = ref.nf4_dequant(q, n, a).view(np.uint16)
+        t = ref.nf4_dequant_numpy(q, n, a).view(np.uint16)
+        assert np.array_equal(c, t)
+
+    check()
