@@ -605,7 +605,17 @@ def main():
         },
     }
 
-    if not a.no_bs1:
+    def attempt(key, fn):
+        """A leg beside the headline measurement: if it fails, the line is still printed and carries the failure in the
+        leg's place (the traceback goes to stderr)."""
+        try:
+            result[key] = fn()
+        except Exception as exc:
+            import traceback
+            traceback.print_exc()
+            result[key] = {"error": f"{type(exc).__name__}: {exc}"}
+
+    def bs1_leg():
         # configs[1] of BASELINE.json: bs=1 greedy decode, seq_len 256 (per GPU when N > 1)
         main_step.graph = None
         bs1 = DecodeStep(lib, ep_mod, 1, a.ctx, a.layers, rank, world, device, weights_from=main_step,
@@ -614,22 +624,22 @@ def main():
         torch.cuda.synchronize()
         capture(bs1)
         dt1 = timed(bs1, a.steps, a.warmup, world)
-        result["bs1"] = {"value": world * a.steps / dt1, "unit": "tokens/s", "ms_per_step": dt1 / a.steps * 1e3,
-                         "workload": f"bs=1 per GPU (global {world}), ctx {a.ctx}: BASELINE configs[1]" if world == 1
-                         else f"bs=1 per GPU (global {world}), ctx {a.ctx}, EP{world}"}
+        out = {"value": world * a.steps / dt1, "unit": "tokens/s", "ms_per_step": dt1 / a.steps * 1e3,
+               "workload": f"bs=1 per GPU (global {world}), ctx {a.ctx}: BASELINE configs[1]" if world == 1
+               else f"bs=1 per GPU (global {world}), ctx {a.ctx}, EP{world}"}
         if rank == 0 and world == 1 and not a.no_roofline:
             bs1.graph = None
             r1, act1 = roofline_gate_up(bs1)
-            result["bs1"]["roofline_gate_up"] = {"achieved": r1["gate_up"]["gbs"], "frac": r1["gate_up"]["gbs"] / HBM_PEAK_GBS,
-                                                 "avg_us": r1["gate_up"]["avg_us"], "down_gbs": r1["down"]["gbs"],
-                                                 "down_avg_us": r1["down"]["avg_us"]}
-        del bs1
+            out["roofline_gate_up"] = {"achieved": r1["gate_up"]["gbs"], "frac": r1["gate_up"]["gbs"] / HBM_PEAK_GBS,
+                                       "avg_us": r1["gate_up"]["avg_us"], "down_gbs": r1["down"]["gbs"],
+                                       "down_avg_us": r1["down"]["avg_us"]}
+        return out
 
-    if rank == 0 and world == 1 and not a.no_roofline:
+    def roofline_leg():
         r, active = roofline_gate_up(main_step)
         traffic, traffic_src = profiled_traffic()
         tflops = a.batch_per_gpu * TOPK * GATE_UP_FLOPS_PER_PAIR / (r["gate_up"]["avg_us"] * 1e-6) / 1e12
-        result["roofline"] = {
+        return {
             "bound": "hbm", "kernel": "moe_gemm_stream_kernel<gate_up> (NF4 dequant fused into the grouped GEMM)",
             "achieved": r["gate_up"]["gbs"], "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": r["gate_up"]["gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -640,17 +650,23 @@ def main():
             # the same launch priced against the matrix cores: decode at 4 tokens per expert is far left of the ridge
             "mfma": {"achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS},
         }
-    if rank == 0 and world == 1 and a.prefill_tokens > 0:
-        result["prefill"] = prefill_leg(lib, main_step, device, a.prefill_tokens)
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline()
-    if rank == 0 and world == 1 and a.full_layer_leg and a.prefill_tokens > 0:
-        result["full_decoder_stack_prompt"] = full_layer_prompt_leg(lib, main_step, a.prefill_tokens, a.layers, device)
-    if rank == 0 and world == 1 and a.full_layer_leg:
-        result["full_decoder_stack"] = [full_layer_leg(lib, main_step, b, a.ctx, a.layers, device, a.steps, a.warmup)
-                                        for b in (a.batch_per_gpu, 1)]
-    if rank == 0 and world == 1 and a.load_leg:
-        result["load"] = load_leg(device)
+
+    if not a.no_bs1:
+        attempt("bs1", bs1_leg)
+    single = rank == 0 and world == 1
+    if single and not a.no_roofline:
+        attempt("roofline", roofline_leg)
+    if single and a.prefill_tokens > 0:
+        attempt("prefill", lambda: prefill_leg(lib, main_step, device, a.prefill_tokens))
+    if single and not a.no_cpu_baseline:
+        attempt("cpu_baseline", cpu_baseline)
+    if single and a.full_layer_leg and a.prefill_tokens > 0:
+        attempt("full_decoder_stack_prompt", lambda: full_layer_prompt_leg(lib, main_step, a.prefill_tokens, a.layers, device))
+    if single and a.full_layer_leg:
+        attempt("full_decoder_stack", lambda: [full_layer_leg(lib, main_step, b, a.ctx, a.layers, device, a.steps, a.warmup)
+                                               for b in (a.batch_per_gpu, 1)])
+    if single and a.load_leg:
+        attempt("load", lambda: load_leg(device))
 
     if rank == 0:
         print(json.dumps(result), flush=True)
