@@ -5,7 +5,7 @@ import gpt_oss_vllm_amd
 from gpt_oss_vllm_amd import lib
 Hq, Hkv, D, BLOCK, LAYERS = 64, 8, 64, 16, 24
 d = torch.device('cuda')
-for B, ctx in ((1, 256), (32, 256), (32, 2048), (256, 256)):
+for B, ctx in ((1, 256), (32, 256), (1, 257), (32, 257), (32, 512), (4, 1024), (32, 1024), (32, 2048), (1, 8192), (256, 256)):
     nb = (ctx + BLOCK - 1) // BLOCK
     bt = torch.randperm(B * nb, device=d).to(torch.int32).reshape(B, nb).contiguous()
     cl = torch.full((B,), ctx, dtype=torch.int32, device=d)

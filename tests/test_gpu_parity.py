@@ -240,7 +240,11 @@ def test_moe_empty_batch_and_errors(m355, cuda):
 
 
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("ctx", [[1], [256, 17, 100], [700, 3, 257, 512], [0, 5]])
+# 32 sequences fill the chip by themselves, so contexts of three and four rounds of 256 tokens stay in one workgroup
+_CTX32 = [1000, 1, 256, 257, 513, 768, 769, 1024, 5, 300, 900, 640] + [37 * i % 1024 + 1 for i in range(20)]
+
+
+@pytest.mark.parametrize("ctx", [[1], [256, 17, 100], [700, 3, 257, 512], [0, 5], [300, 2, 512, 257], _CTX32, _CTX32[:31] + [0]])
 def test_paged_attention_vs_oracle(ctx, ref, m355, cuda):
     """No reference output exists for attention (it lives in FlashAttention-2): parity unpinned, checked
     against the oracle's fp32 softmax attention.  Tolerance 2e-3 * max|out| + 1e-5."""
@@ -259,6 +263,30 @@ def test_paged_attention_vs_oracle(ctx, ref, m355, cuda):
     want = ref.paged_attn_decode(q, kc, vc, bt, cl, scale)
     out = m355.paged_attn_decode(_to_dev(q, cuda), _to_dev(kc, cuda), _to_dev(vc, cuda), _to_dev(bt, cuda),
                                  _to_dev(cl, cuda), max_ctx=max_ctx, scale=scale)
+    torch.cuda.synchronize()
+    _close(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("B,max_len,window", [(3, 512, 128), (3, 512, 300), (32, 1024, 300), (32, 700, 0), (2, 2000, 700)])
+def test_paged_attention_rounds_sinks_window_vs_oracle(B, max_len, window, ref, m355, cuda):
+    """Contexts of several 256-token rounds (one workgroup per context up to two rounds, up to four when the batch fills
+    the chip, partitions + merge beyond) with sinks and a sliding window that starts inside any of the rounds."""
+    Hq, Hkv, D, bs = 64, 8, 64, 16
+    sd = ref.stream_seed(B, max_len, window, 4711)
+    lens = (ref.uniform01(ref.stream_seed(sd, 5), B) * max_len).astype(np.int32) + 1
+    lens[0] = max_len
+    max_blocks = (max_len + bs - 1) // bs
+    nblk = B * max_blocks + 1
+    q = ref.normal_f16(ref.stream_seed(sd, 1), (B, Hq, D))
+    kc = ref.normal_f16(ref.stream_seed(sd, 2), (nblk, bs, Hkv, D))
+    vc = ref.normal_f16(ref.stream_seed(sd, 3), (nblk, bs, Hkv, D))
+    sinks = ref.normal_f16(ref.stream_seed(sd, 6), (Hq,))
+    perm = np.argsort(ref.uniform01(ref.stream_seed(sd, 4), nblk)).astype(np.int32)
+    bt = perm[:B * max_blocks].reshape(B, max_blocks).copy()
+    scale = D ** -0.5
+    want = ref.paged_attn_decode_ex(q, kc, vc, bt, lens, scale, sinks=sinks, window=window)
+    out = m355.paged_attn_decode(_to_dev(q, cuda), _to_dev(kc, cuda), _to_dev(vc, cuda), _to_dev(bt, cuda),
+                                 _to_dev(lens, cuda), max_ctx=max_len, scale=scale, sinks=_to_dev(sinks, cuda), window=window)
     torch.cuda.synchronize()
     _close(out.cpu().numpy(), want)
 
