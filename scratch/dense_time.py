@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 for N, K in ((5120, 2880), (2880, 4096)):
     w = (torch.randn((N, K), device=dev) * 0.05).half()
     b = torch.randn((N,), device=dev).half()
-    for T in (64, 128, 256, 512, 1024, 2048, 4096, 8192):
+    for T in ([int(a) for a in sys.argv[1:]] or (64, 128, 256, 512, 1024, 2048, 4096, 8192)):
         x = torch.randn((T, K), device=dev).half()
         out = torch.empty((T, N), device=dev, dtype=torch.float16)
         for _ in range(3):
