@@ -320,8 +320,10 @@ def full_layer_leg(lib, main_step, batch, ctx, layers, device, steps, warmup):
 
     def run():
         resid, delta = x0, None
-        for lyr, kc, vc in stack:
-            resid, delta = lyr.forward(resid, delta, positions, slots, block_tables, ctx_lens, kc, vc, cos, sin, max_ctx=ctx + 1)
+        for i, (lyr, kc, vc) in enumerate(stack):
+            # every layer but the last leaves its combine step to the next layer's first kernel
+            resid, delta = lyr.forward(resid, delta, positions, slots, block_tables, ctx_lens, kc, vc, cos, sin, max_ctx=ctx + 1,
+                                       defer_combine=i + 1 < len(stack))
         return resid, delta
 
     run()

@@ -2,16 +2,21 @@
 // RMSNorm, and rotary embedding + KV-cache write.  Both are a few KB per token: latency, not bandwidth.
 // Arithmetic follows transformers' modeling_gpt_oss.py (GptOssRMSNorm.forward, _apply_rotary_emb) operation by
 // operation, with fp16 tensors where that code has model-dtype tensors, so every intermediate rounds where theirs does.
-#include "common.h"
+#include "moe_shared.h"
 
 namespace m355 {
 
 constexpr int NORM_THREADS = 256;
 
 // r = fp16(x + delta) (or x); y = fp16(w * (float(r) * rsqrt(mean(float(r)^2) + eps))).  One workgroup per token.
+// COMBINE: delta is not read but formed here, as the MoE combine step forms it (combine_chunk: same bits), from the
+// expert outputs cy / cinv / cw that a forward called with M355_FLAG_SKIP_COMBINE left in its workspace.
+template <bool COMBINE>
 __global__ __launch_bounds__(NORM_THREADS) void add_rmsnorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ delta,
                                                                    const half_t* __restrict__ weight, float eps, int H,
-                                                                   half_t* __restrict__ resid_out, half_t* __restrict__ y) {
+                                                                   half_t* __restrict__ resid_out, half_t* __restrict__ y,
+                                                                   const half_t* __restrict__ cy, const int32_t* __restrict__ cinv,
+                                                                   const float* __restrict__ cw, int k_top, int fp16_mode) {
     __shared__ float part[NORM_THREADS / 64];
     const int t = blockIdx.x, tid = threadIdx.x;
     const int chunks = H / 8;
@@ -25,7 +30,11 @@ __global__ __launch_bounds__(NORM_THREADS) void add_rmsnorm_kernel(const half_t*
         const int c = tid + u * NORM_THREADS;
         if (c < chunks) {
             half8_t v = xr[c];
-            if (dr) v = v + dr[c];   // fp16 add, rounded, as the residual tensors are
+            if constexpr (COMBINE) {
+                v = v + combine_chunk<4>(cy, cinv, cw, t, c, H, k_top, fp16_mode);
+            } else {
+                if (dr) v = v + dr[c];   // fp16 add, rounded, as the residual tensors are
+            }
             r[u] = v;
 #pragma unroll
             for (int j = 0; j < 8; j++) ss += (float)v[j] * (float)v[j];
@@ -117,8 +126,30 @@ extern "C" int m355_add_rmsnorm(const void* x_f16, const void* delta_f16, const 
     if (!aligned(x_f16, 16) || !aligned(weight_f16, 16) || !aligned(y_f16, 16) || (delta_f16 && !aligned(delta_f16, 16)) ||
         (resid_out_f16 && !aligned(resid_out_f16, 16)))
         return fail(-3, "m355_add_rmsnorm: buffers must be 16-byte aligned");
-    add_rmsnorm_kernel<<<dim3(T), dim3(NORM_THREADS), 0, (hipStream_t)stream>>>(
-        (const half_t*)x_f16, (const half_t*)delta_f16, (const half_t*)weight_f16, eps, H, (half_t*)resid_out_f16, (half_t*)y_f16);
+    add_rmsnorm_kernel<false><<<dim3(T), dim3(NORM_THREADS), 0, (hipStream_t)stream>>>(
+        (const half_t*)x_f16, (const half_t*)delta_f16, (const half_t*)weight_f16, eps, H, (half_t*)resid_out_f16, (half_t*)y_f16,
+        nullptr, nullptr, nullptr, 0, 0);
+    M355_LAUNCH_CHECK("add_rmsnorm_kernel");
+    return 0;
+}
+
+extern "C" int m355_moe_combine_add_rmsnorm(const void* moe_workspace, size_t ws_bytes, int T, int k, int FF, int E_local,
+                                            const float* w, int flags, const void* x_f16, const void* weight_f16, float eps,
+                                            int H, void* resid_out_f16, void* y_f16, m355_stream_t stream) {
+    if (T == 0) return 0;
+    if (!moe_workspace || !w || !x_f16 || !weight_f16 || !y_f16) return fail(-1, "m355_moe_combine_add_rmsnorm: null pointer");
+    if (T < 0 || k <= 0 || k > 32 || FF <= 0 || E_local <= 0 || H <= 0 || (H % 8) || H > 8 * NORM_THREADS * 4)
+        return fail(-2, "m355_moe_combine_add_rmsnorm: unsupported shape T=%d k=%d H=%d FF=%d E_local=%d (need H %% 8 == 0, H <= %d)",
+                    T, k, H, FF, E_local, 8 * NORM_THREADS * 4);
+    if (!aligned(moe_workspace, 256) || !aligned(x_f16, 16) || !aligned(weight_f16, 16) || !aligned(y_f16, 16) ||
+        (resid_out_f16 && !aligned(resid_out_f16, 16)))
+        return fail(-3, "m355_moe_combine_add_rmsnorm: workspace 256-byte, other buffers 16-byte aligned");
+    const MoeWorkspace ws = carve_workspace(const_cast<void*>(moe_workspace), T, k, H, FF, E_local);
+    if (ws_bytes < ws.bytes)
+        return fail(-6, "m355_moe_combine_add_rmsnorm: the workspace of this forward has %zu bytes, %zu given", ws.bytes, ws_bytes);
+    add_rmsnorm_kernel<true><<<dim3(T), dim3(NORM_THREADS), 0, (hipStream_t)stream>>>(
+        (const half_t*)x_f16, nullptr, (const half_t*)weight_f16, eps, H, (half_t*)resid_out_f16, (half_t*)y_f16, ws.y, ws.inv, w,
+        k, (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0);
     M355_LAUNCH_CHECK("add_rmsnorm_kernel");
     return 0;
 }

@@ -750,54 +750,15 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
 #undef M355_CODES_OF
 }
 
-// out[t][c] = sum over the token's local pairs, in k order.  FP16 mode rounds as the reference's fp16
-// tensors do: w -> fp16, product -> fp16, running sum -> fp16.  The pairs are taken KB at a time: their positions and
-// weights are requested together, then their y rows together, and only the arithmetic runs in k order, so a batch
-// costs two memory round trips instead of two per pair.
+// out[t][c] = sum over the token's local pairs, in k order (combine_chunk, shared with the fused combine + norm kernel).
 template <int KB>
 __global__ __launch_bounds__(256) void moe_combine_kernel(const half_t* __restrict__ y, const int32_t* __restrict__ inv,
                                                           const float* __restrict__ w, int H, int k_top, int fp16_mode,
                                                           half_t* __restrict__ out) {
     const int t = blockIdx.x;
     const int chunks = H / 8;
-    for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) acc[j] = 0.f;
-        for (int k0 = 0; k0 < k_top; k0 += KB) {
-            int pos[KB];
-            float wf[KB];
-            half8_t yv[KB];
-#pragma unroll
-            for (int i = 0; i < KB; i++) {
-                const bool in = k0 + i < k_top;
-                pos[i] = in ? inv[t * k_top + k0 + i] : -1;
-                wf[i] = in ? w[t * k_top + k0 + i] : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < KB; i++)
-                if (pos[i] >= 0) yv[i] = reinterpret_cast<const half8_t*>(y + (int64_t)pos[i] * H)[c];
-#pragma unroll
-            for (int i = 0; i < KB; i++) {
-                if (pos[i] < 0) continue;
-                if (fp16_mode) {
-                    const float w16 = (float)(half_t)wf[i];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        const float prod = (float)(half_t)(w16 * (float)yv[i][j]);
-                        acc[j] = (float)(half_t)(acc[j] + prod);
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) acc[j] += wf[i] * (float)yv[i][j];
-                }
-            }
-        }
-        half8_t o;
-#pragma unroll
-        for (int j = 0; j < 8; j++) o[j] = (half_t)acc[j];
-        reinterpret_cast<half8_t*>(out + (int64_t)t * H)[c] = o;
-    }
+    for (int c = threadIdx.x; c < chunks; c += blockDim.x)
+        reinterpret_cast<half8_t*>(out + (int64_t)t * H)[c] = combine_chunk<KB>(y, inv, w, t, c, H, k_top, fp16_mode);
 }
 
 static int gemm_lds_bytes(int K, int mt_rows) { return LUT_BYTES + RED_BYTES + mt_rows * (K * 2 + XS_PAD); }

@@ -50,6 +50,53 @@ struct StageParams {
     const half_t* bias;
 };
 
+
+// The combine step for 8 columns of one token: sum over the token's local pairs, in k order.  FP16 mode rounds as the
+// reference's fp16 tensors do: w -> fp16, product -> fp16, running sum -> fp16.  The pairs are taken KB at a time: their
+// positions and weights are requested together, then their y rows together, and only the arithmetic runs in k order, so a
+// batch costs two memory round trips instead of two per pair.  Shared by the combine kernel and by the kernel that fuses
+// the combine with the residual add and RMSNorm that follow it, so both give the same bits.
+template <int KB>
+__device__ __forceinline__ half8_t combine_chunk(const half_t* __restrict__ y, const int32_t* __restrict__ inv,
+                                                 const float* __restrict__ w, int t, int c, int H, int k_top, int fp16_mode) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) acc[j] = 0.f;
+    for (int k0 = 0; k0 < k_top; k0 += KB) {
+        int pos[KB];
+        float wf[KB];
+        half8_t yv[KB];
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            const bool in = k0 + i < k_top;
+            pos[i] = in ? inv[t * k_top + k0 + i] : -1;
+            wf[i] = in ? w[t * k_top + k0 + i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < KB; i++)
+            if (pos[i] >= 0) yv[i] = reinterpret_cast<const half8_t*>(y + (int64_t)pos[i] * H)[c];
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            if (pos[i] < 0) continue;
+            if (fp16_mode) {
+                const float w16 = (float)(half_t)wf[i];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float prod = (float)(half_t)(w16 * (float)yv[i][j]);
+                    acc[j] = (float)(half_t)(acc[j] + prod);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[j] += wf[i] * (float)yv[i][j];
+            }
+        }
+    }
+    half8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; j++) o[j] = (half_t)acc[j];
+    return o;
+}
+
 // Token tiles of the large-M kernel: up to this many rows of one expert share one pass over the expert's weights.
 constexpr int TILE_ROWS = 256;
 

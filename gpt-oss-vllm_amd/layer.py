@@ -75,6 +75,23 @@ def validate_paging(block_tables: torch.Tensor, slots: torch.Tensor, ctx_lens: t
 # ---------------------------------------------------------------------------------------------
 # One gpt-oss decoder layer at decode time, as a fixed sequence of library calls on preallocated buffers
 # ---------------------------------------------------------------------------------------------
+class PendingCombine:
+    """The expert output of a layer whose forward skipped the combine step: the experts' rows and the routing still sit
+    in that layer's workspace.  The next layer consumes it in its first kernel; materialize() runs the plain combine."""
+
+    def __init__(self, layer):
+        self.layer, self.workspace, self.w = layer, layer.moe_ws, layer.wts
+        self.FF, self.E, self.flags = layer.FF, layer.E, 0
+
+    def materialize(self):
+        lay, lib, w = self.layer, self.layer.lib, self.layer.w
+        skip = lib.FLAG_SKIP_ROUTE | lib.FLAG_SKIP_GATE_UP | lib.FLAG_SKIP_DOWN
+        lib.moe_nf4_forward(lay.h2, lay.ids, lay.wts, w["w13_q"], w["w13_absmax"], w["w2_q"], w["w2_absmax"], E_local=lay.E,
+                            e_first=0, H=lay.H, FF=lay.FF, workspace=lay.moe_ws, out=lay.moe_out, act_mode=lay.act_mode,
+                            flags=self.flags | skip, b13=w.get("b13"), b2=w.get("b2"))
+        return lay.moe_out
+
+
 class GptOssDecodeLayer:
     """GptOssDecoderLayer.forward (transformers models/gpt_oss/modeling_gpt_oss.py:347-379) for one new token per
     sequence: RMSNorm -> fused q/k/v projection -> rotary + KV-cache write -> paged attention (sinks, optional sliding
@@ -144,15 +161,23 @@ class GptOssDecodeLayer:
                                                    act_mode=self.act_mode, flags=0, b13=w.get("b13"), b2=w.get("b2"))
         return resid2, moe_out
 
-    def forward(self, resid_in, delta, positions, slots, block_tables, ctx_lens, kcache, vcache, cos, sin, max_ctx: int):
+    def forward(self, resid_in, delta, positions, slots, block_tables, ctx_lens, kcache, vcache, cos, sin, max_ctx: int,
+                defer_combine: bool = False):
         """resid_in [T][H]: the residual stream entering the layer, delta: the previous layer's expert output still to
-        be added (None for the first layer).  ctx_lens counts the new token.  Returns (residual stream after
-        attention, expert output): their sum is the layer's output."""
+        be added (None for the first layer; a PendingCombine when that layer ran with defer_combine).  ctx_lens counts
+        the new token.  Returns (residual stream after attention, expert output): their sum is the layer's output.
+        defer_combine: the expert output is returned as a PendingCombine (the experts' rows still unsummed in this
+        layer's workspace); the next layer's first kernel then forms it together with the residual add and its
+        RMSNorm, one launch less per layer, same bits."""
         lib, w = self.lib, self.w
         T = resid_in.shape[0]
         if T != self.T:
             raise ValueError(f"built for {self.T} tokens per step, got {T}")
-        lib.add_rmsnorm(resid_in, delta, w["ln1"], self.eps, resid_out=self.resid, out=self.h1)
+        if isinstance(delta, PendingCombine):
+            lib.moe_combine_add_rmsnorm(delta.workspace, delta.w, FF=delta.FF, E_local=delta.E, flags=delta.flags, x=resid_in,
+                                        weight=w["ln1"], eps=self.eps, resid_out=self.resid, out=self.h1)
+        else:
+            lib.add_rmsnorm(resid_in, delta, w["ln1"], self.eps, resid_out=self.resid, out=self.h1)
         lib.linear_f16(self.h1, w["wqkv"], w.get("bqkv"), out=self.qkv)
         lib.rope_kv_write(self.qkv, cos, sin, positions, slots, kcache, vcache, Hq=self.Hq, Hkv=self.Hkv, D=self.D, q_out=self.q)
         need = lib.paged_attn_workspace_bytes(T, self.Hq, self.D, max_ctx)
@@ -164,6 +189,8 @@ class GptOssDecodeLayer:
         lib.add_rmsnorm(self.resid2, None, w["ln2"], self.eps, out=self.h2)
         lib.moe_nf4_forward_routed(self.h2, w["router_w"], w.get("router_b"), self.k, w["w13_q"], w["w13_absmax"], w["w2_q"],
                                    w["w2_absmax"], E_local=self.E, e_first=0, H=self.H, FF=self.FF, ids=self.ids, w=self.wts,
-                                   workspace=self.moe_ws, out=self.moe_out, act_mode=self.act_mode, flags=0,
-                                   b13=w.get("b13"), b2=w.get("b2"))
+                                   workspace=self.moe_ws, out=self.moe_out, act_mode=self.act_mode,
+                                   flags=lib.FLAG_SKIP_COMBINE if defer_combine else 0, b13=w.get("b13"), b2=w.get("b2"))
+        if defer_combine:
+            return self.resid2, PendingCombine(self)
         return self.resid2, self.moe_out

@@ -27,7 +27,7 @@ EXPORTS = (
     "m355_paged_attn_workspace_bytes", "m355_ep_row_bytes", "m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce",
     "m355_add_rmsnorm", "m355_rope_kv_write", "m355_linear_f16", "m355_paged_attn_decode_ex",
     "m355_repack_nf4_ex", "m355_moe_nf4_forward_ex", "m355_moe_nf4_forward_q8", "m355_repack_absmax_u8",
-    "m355_moe_nf4_forward_routed", "m355_attn_prefill",
+    "m355_moe_nf4_forward_routed", "m355_attn_prefill", "m355_moe_combine_add_rmsnorm",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -87,6 +87,8 @@ def load() -> ctypes.CDLL:
     L.m355_linear_f16.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp, vp]
     L.m355_linear_f16.restype = i32
     L.m355_add_rmsnorm.argtypes = [vp, vp, vp, ctypes.c_float, i32, i32, vp, vp, vp]
+    L.m355_moe_combine_add_rmsnorm.argtypes = [vp, sz, i32, i32, i32, i32, vp, i32, vp, vp, ctypes.c_float, i32, vp, vp, vp]
+    L.m355_moe_combine_add_rmsnorm.restype = i32
     L.m355_rope_kv_write.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     for fn in ("m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce", "m355_nf4_dequant", "m355_repack_nf4", "m355_router_topk", "m355_topk_softmax",
                "m355_moe_nf4_forward", "m355_paged_attn_decode", "m355_add_rmsnorm", "m355_rope_kv_write"):
@@ -400,6 +402,26 @@ def add_rmsnorm(x: torch.Tensor, delta: Optional[torch.Tensor], weight: torch.Te
                                    _dev(weight, torch.float16, "weight"), float(eps), T, H,
                                    None if resid_out is None else _dev(resid_out, torch.float16, "resid_out"),
                                    _dev(out, torch.float16, "out"), _stream()), "m355_add_rmsnorm")
+    return out
+
+
+def moe_combine_add_rmsnorm(moe_workspace: torch.Tensor, w: torch.Tensor, *, FF: int, E_local: int, flags: int,
+                            x: torch.Tensor, weight: torch.Tensor, eps: float, resid_out: Optional[torch.Tensor] = None,
+                            out: Optional[torch.Tensor] = None):
+    """add_rmsnorm(x, delta) where delta is what the combine step of a MoE forward would write: the forward (same T, k, H,
+    FF, E_local, `flags` its flags) ran with FLAG_SKIP_COMBINE on `moe_workspace`, `w` are its routing weights [T][k].
+    m355_moe_combine_add_rmsnorm."""
+    T, H = x.shape
+    k = w.shape[1]
+    if w.shape[0] != T:
+        raise ValueError(f"w has {w.shape[0]} rows, x has {T}")
+    if out is None:
+        out = torch.empty_like(x)
+    _check(load().m355_moe_combine_add_rmsnorm(
+        _dev(moe_workspace, torch.uint8, "moe_workspace"), moe_workspace.numel(), T, k, FF, E_local, _dev(w, torch.float32, "w"),
+        int(flags), _dev(x, torch.float16, "x"), _dev(weight, torch.float16, "weight"), float(eps), H,
+        None if resid_out is None else _dev(resid_out, torch.float16, "resid_out"), _dev(out, torch.float16, "out"), _stream()),
+        "m355_moe_combine_add_rmsnorm")
     return out
 
 

@@ -231,6 +231,14 @@ M355_API int m355_linear_f16(const void* x_f16, int T, const void* w_f16, const 
                              const void* resid_f16, void* out_f16, m355_stream_t stream);
 M355_API int m355_add_rmsnorm(const void* x_f16, const void* delta_f16, const void* weight_f16, float eps, int T, int H,
                               void* resid_out_f16, void* y_f16, m355_stream_t stream);
+/* m355_add_rmsnorm with the MoE combine step in front: the delta is formed here, exactly as the combine forms it, from
+ * what a forward of the same T, k, H, FF, E_local called with M355_FLAG_SKIP_COMBINE left in `moe_workspace` (w: that
+ * forward's routing weights, flags: its M355_FLAG_FP16_COMBINE), so a decoder stack spends one launch less per layer:
+ * expert outputs -> residual add -> the next layer's RMSNorm (GptOssDecoderLayer.forward, modeling_gpt_oss.py, the
+ * `residual + hidden_states` after the MLP followed by the next layer's input_layernorm). */
+M355_API int m355_moe_combine_add_rmsnorm(const void* moe_workspace, size_t ws_bytes, int T, int k, int FF, int E_local,
+                                          const float* w, int flags, const void* x_f16, const void* weight_f16, float eps,
+                                          int H, void* resid_out_f16, void* y_f16, m355_stream_t stream);
 M355_API int m355_rope_kv_write(const void* qkv_f16, const void* cos_f16, const void* sin_f16, const int32_t* positions,
                                 const int64_t* slots, int T, int Hq, int Hkv, int D, int block_size, int max_pos,
                                 void* q_out_f16, void* kcache_f16, void* vcache_f16, m355_stream_t stream);

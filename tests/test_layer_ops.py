@@ -382,6 +382,74 @@ def test_gpu_whole_decoder_layer_vs_transformers(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,fp16", [(1, 0), (5, 1), (33, 0)])
+def test_gpu_combine_fused_into_add_rmsnorm(T, fp16):
+    """m355_moe_combine_add_rmsnorm (the combine step formed inside the next residual add + RMSNorm) against the two
+    separate launches, bit for bit: forward with and without M355_FLAG_SKIP_COMBINE on the same routing."""
+    from gpt_oss_vllm_amd import lib
+    cuda = torch.device("cuda:0")
+    E, k, H, FF = 8, 3, 256, 192
+    sd = oracle_ref.stream_seed(T, fp16, 515)
+    layer_np = oracle_ref.synth_layer(sd, E, H, FF)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    w13_q = torch.stack([lib.repack_nf4(dev(layer_np["w13_q"][e]), dev(layer_np["w13_absmax"][e]), 2 * FF, H)[0] for e in range(E)])
+    w13_a = torch.stack([lib.repack_nf4(dev(layer_np["w13_q"][e]), dev(layer_np["w13_absmax"][e]), 2 * FF, H)[1] for e in range(E)])
+    w2_q = torch.stack([lib.repack_nf4(dev(layer_np["w2_q"][e]), dev(layer_np["w2_absmax"][e]), H, FF)[0] for e in range(E)])
+    w2_a = torch.stack([lib.repack_nf4(dev(layer_np["w2_q"][e]), dev(layer_np["w2_absmax"][e]), H, FF)[1] for e in range(E)])
+    x = dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 1), (T, H)))
+    resid = dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 3), (T, H)))
+    lnw = dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 4), (H,), 0.1)) + 1
+    ids, w = lib.topk_softmax(dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 2), (T, E), 1.5)), k)
+    ws = torch.empty(max(256, lib.moe_workspace_bytes(T, k, H, FF, E)), dtype=torch.uint8, device=cuda)
+    kw = dict(E_local=E, e_first=0, H=H, FF=FF, workspace=ws)
+    delta = lib.moe_nf4_forward(x, ids, w, w13_q, w13_a, w2_q, w2_a, flags=fp16, **kw)
+    r_want = torch.empty_like(resid)
+    y_want = lib.add_rmsnorm(resid, delta, lnw, 1e-5, resid_out=r_want)
+    lib.moe_nf4_forward(x, ids, w, w13_q, w13_a, w2_q, w2_a, flags=fp16 | lib.FLAG_SKIP_COMBINE, **kw)
+    r_got = torch.empty_like(resid)
+    y_got = lib.moe_combine_add_rmsnorm(ws, w, FF=FF, E_local=E, flags=fp16, x=resid, weight=lnw, eps=1e-5, resid_out=r_got)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y_want.float()).all() and delta.float().abs().max() > 0
+    assert torch.equal(r_got, r_want) and torch.equal(y_got, y_want)
+    with pytest.raises(lib.Mi355LibraryError):   # a workspace too small for this forward
+        lib.moe_combine_add_rmsnorm(ws[:256], w, FF=FF, E_local=E, flags=fp16, x=resid, weight=lnw, eps=1e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_decoder_layers_deferred_combine_equals_plain():
+    """Two decode steps through a layer chained to itself (the second consumes the first's expert output): with the
+    combine deferred into the next add + RMSNorm the results equal the plain path bit for bit."""
+    from gpt_oss_vllm_amd import layer
+    cuda = torch.device("cuda:0")
+    lyr, p = _decoder_layer("full", 1)
+    L = p["L"]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    block_size = 16
+    nblk = (L + 2 + block_size - 1) // block_size
+    perm = np.random.default_rng(5).permutation(nblk).astype(np.int32)
+    cos, sin = layer.rope_tables(512)
+    cos, sin = cos.to(cuda), sin.to(cuda)
+    slot_of = lambda t: int(perm[t // block_size]) * block_size + t % block_size
+    x = dev(p["x"])
+    outs = []
+    for defer in (False, True):
+        kc = torch.zeros((nblk, block_size, p["Hkv"], p["D"]), dtype=torch.float16, device=cuda)
+        vc = torch.zeros_like(kc)
+        lyr.write_kv_only(x[:L].contiguous(), torch.arange(L, dtype=torch.int32, device=cuda),
+                          torch.tensor([slot_of(t) for t in range(L)], dtype=torch.int64, device=cuda), kc, vc, cos, sin)
+        args = lambda t: (torch.tensor([t], dtype=torch.int32, device=cuda), torch.tensor([slot_of(t)], dtype=torch.int64, device=cuda),
+                          dev(perm[None, :].copy()), torch.tensor([t + 1], dtype=torch.int32, device=cuda), kc, vc, cos, sin)
+        r1, d1 = lyr.forward(x[L:].contiguous(), None, *args(L), max_ctx=L + 2, defer_combine=defer)
+        assert isinstance(d1, layer.PendingCombine) == defer
+        r1 = r1.clone()
+        r2, d2 = lyr.forward(r1, d1, *args(L + 1), max_ctx=L + 2, defer_combine=defer)
+        d2 = d2.materialize() if defer else d2
+        torch.cuda.synchronize()
+        outs.append((r2.clone(), d2.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["sliding", "full"])
 def test_gpu_prompt_through_decoder_layer_vs_transformers(name):
     """The prompt pass of the layer: all 201 tokens at once (prompt attention kernel), every output row against
