@@ -6,7 +6,7 @@ from gpt_oss_vllm_amd import lib
 H = 2880; k = 4; L = 24
 d = torch.device('cuda')
 big = torch.empty(512 << 20, dtype=torch.uint8, device=d)   # flushed through L2 between replays
-for T, E in ((1, 32), (8, 32), (32, 32), (64, 32), (32, 128)):
+for T, E in ((32, 32), (32, 128), (64, 128), (128, 128), (256, 128), (256, 32), (512, 32)):
     lay = [dict(x=torch.randn((T, H), device=d).half(), wr=(torch.randn((E, H), device=d) * 0.02).half(),
                 ids=torch.empty((T, k), dtype=torch.int32, device=d), w=torch.empty((T, k), dtype=torch.float32, device=d)) for _ in range(L)]
     def run():
