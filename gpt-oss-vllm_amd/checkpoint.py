@@ -52,14 +52,26 @@ def read_expert(checkpoint_paths: Iterable[str], layer_idx: int, expert_idx: int
     return None
 
 
-def iter_layer_tensors(checkpoint_paths: List[str], layer_idx: int, num_experts: int
-                       ) -> Iterator[Tuple[str, torch.Tensor]]:
-    """(checkpoint name, tensor) pairs of every expert tensor of one layer, in expert order."""
+ZERO_CODE_BYTE = 0x77   # two NF4 codes 7 = 0.0 (patches/streaming_unsloth_bnb.py:101-106)
+
+
+def iter_layer_tensors(checkpoint_paths: List[str], layer_idx: int, num_experts: int, missing: str = "raise",
+                       dims: Optional[Tuple[int, int]] = None) -> Iterator[Tuple[str, torch.Tensor]]:
+    """(checkpoint name, tensor) pairs of every expert tensor of one layer, in expert order.  An expert matrix no shard
+    holds raises KeyError (missing="raise") or, with missing="zeros" and dims=(H, FF), is replaced by an all-zero matrix
+    (every code the NF4 zero, no absmax), which is what the reference substitutes for a missing gate_up
+    (patches/streaming_unsloth_bnb.py:261-264: such an expert contributes nothing)."""
+    if missing not in ("raise", "zeros"):
+        raise ValueError(f"missing={missing!r}: expected 'raise' or 'zeros'")
     for e in range(num_experts):
         for proj in ("gate_up", "down"):
             t = read_expert(checkpoint_paths, layer_idx, e, proj)
             if t is None:
-                raise KeyError(f"{expert_weight_key(layer_idx, e, proj)} is in none of the shards")
+                if missing == "raise" or dims is None:
+                    raise KeyError(f"{expert_weight_key(layer_idx, e, proj)} is in none of the shards")
+                H, FF = dims
+                n = 2 * FF * H if proj == "gate_up" else H * FF
+                t = {"weight": torch.full((n // 2, 1), ZERO_CODE_BYTE, dtype=torch.uint8)}
             key = expert_weight_key(layer_idx, e, proj)
             yield key, t["weight"]
             for sfx in STATE_SUFFIXES:
@@ -67,9 +79,9 @@ def iter_layer_tensors(checkpoint_paths: List[str], layer_idx: int, num_experts:
                     yield f"{key}.{sfx}", t[sfx]
 
 
-def load_layer(method, layer, checkpoint_paths: List[str], layer_idx: int) -> None:
+def load_layer(method, layer, checkpoint_paths: List[str], layer_idx: int, missing: str = "raise") -> None:
     """Fill one FusedMoE layer (already through method.create_weights) from the shards and convert it."""
-    E = layer._m355_dims[0]
-    for name, tensor in iter_layer_tensors(checkpoint_paths, layer_idx, E):
+    E, H, FF = layer._m355_dims
+    for name, tensor in iter_layer_tensors(checkpoint_paths, layer_idx, E, missing=missing, dims=(H, FF)):
         method.weight_loader(layer, None, tensor, name, shard_id=None, expert_id=None)
     method.process_weights_after_loading(layer)

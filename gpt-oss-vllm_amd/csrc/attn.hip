@@ -49,7 +49,8 @@ __device__ __forceinline__ void paged_attn_decode_body(
     const int b = blockIdx.x, hk = blockIdx.y, part = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const int L = ctx_lens[b];
+    // (a length beyond what the block table covers would index past the table: such tokens are not read)
+    const int L = min(ctx_lens[b], max_blocks * block_size);
     // sliding window: the query (position L - 1) sees keys L - window .. L - 1
     const int lo = window > 0 ? max(L - window, 0) : 0;
     const int64_t ob = ((int64_t)b * Hq + hk * ATT_G);
@@ -78,7 +79,9 @@ __device__ __forceinline__ void paged_attn_decode_body(
     auto request = [&](int t0, int npt) {
 #pragma unroll
         for (int j = 0; j < ATT_TILES; j++) {
-            const int t = t0 + min(wave * ATT_WTOK + j * 16 + r, npt - 1);
+            // tokens below the window are masked later; their lanes re-read the window's first row instead, so block
+            // table entries and cache rows of tokens that have left the window are never dereferenced
+            const int t = max(t0 + min(wave * ATT_WTOK + j * 16 + r, npt - 1), lo);
             const int blk = bt[t / block_size];
             const int64_t row = ((int64_t)blk * block_size + t % block_size) * row_stride + hk * ATT_D + 16 * g;
             ka[j] = reinterpret_cast<const u32x4_t*>(kc + row)[0];

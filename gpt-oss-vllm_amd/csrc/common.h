@@ -56,6 +56,11 @@ struct PerDeviceOnce {
     }
 };
 
+// Per-device set-up of each source file (kernel attributes, the static workspace's address), idempotent; the device is
+// current.  m355_init runs them all so that nothing is left to a first call inside a graph capture.
+int moe_device_init(int dev);
+int dense_tile_device_init(int dev);
+
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
 // ---- device helpers ----

@@ -175,6 +175,8 @@ static int dense_tile_device_setup_once(int dev) {
     });
 }
 
+int dense_tile_device_init(int dev) { return dense_tile_device_setup_once(dev); }
+
 // Shapes were checked by the caller (K % 64 == 0, N % 16 == 0, 16-byte aligned x and w, 8-byte aligned bias/resid/out).
 int launch_dense_tile(const half_t* x, const half_t* w, const half_t* bias, const half_t* resid, int T, int N, int K,
                       half_t* out, int cus, hipStream_t st) {

@@ -522,6 +522,9 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
                     rio.w_out[threadIdx.x] = wl[threadIdx.x];
                 }
             }
+            // il / wl live in the buffer that inline_route() clears first (its per-expert masks): every read above
+            // must have returned before any wave starts clearing
+            __syncthreads();
         } else {
             if ((int)threadIdx.x < rio.P) my_e = rio.ids[threadIdx.x] - rio.e_first;
         }
@@ -804,6 +807,13 @@ static int device_setup(int dev, int* cus) {
 static int tile_gemm_device_setup_once(int dev) {
     static PerDeviceOnce once;
     return once.run(dev, [] { return tile_gemm_device_setup(); });
+}
+
+// Everything the MoE entry points set up once per device, for m355_init (the device is current).
+int moe_device_init(int dev) {
+    int cus = 0;
+    if (int rc = device_setup(dev, &cus)) return rc;
+    return tile_gemm_device_setup_once(dev);
 }
 
 // mean (token, k) pairs per local expert from which the tile kernel takes over

@@ -57,9 +57,14 @@ __device__ __forceinline__ void topk_softmax_wave(float* logit, int E, int k, in
             if (v > bv || (v == bv && e < bi)) { bv = v; bi = e; }   // NaN logits never win
         }
         wave_argmax(bv, bi);
-        if (bi == 0x7fffffff) bi = j;   // all remaining are NaN / -inf: fall back to a valid id
+        if (bi == 0x7fffffff) {   // every remaining logit is NaN: the lowest id that has not been picked yet
+            for (int c = 0; c <= j; c++) {
+                if (!__ballot(lane < j && myid == c)) { bi = c; break; }
+            }
+        }
         if (lane == j) { myv = bv; myid = bi; }
-        if (lane == 0 && bi < E) logit[bi] = -INFINITY;
+        // a picked entry becomes NaN, which never wins again (a -inf would tie with logits that are -inf themselves)
+        if (lane == 0 && bi < E) logit[bi] = __builtin_nanf("");
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }

@@ -27,7 +27,7 @@ EXPORTS = (
     "m355_paged_attn_workspace_bytes", "m355_ep_row_bytes", "m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce",
     "m355_add_rmsnorm", "m355_rope_kv_write", "m355_linear_f16", "m355_paged_attn_decode_ex",
     "m355_repack_nf4_ex", "m355_moe_nf4_forward_ex", "m355_moe_nf4_forward_q8", "m355_repack_absmax_u8",
-    "m355_moe_nf4_forward_routed", "m355_attn_prefill", "m355_moe_combine_add_rmsnorm",
+    "m355_moe_nf4_forward_routed", "m355_attn_prefill", "m355_moe_combine_add_rmsnorm", "m355_init",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -49,6 +49,8 @@ def load() -> ctypes.CDLL:
     L = ctypes.CDLL(LIB_PATH)
     vp, i32, i64, f32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
     L.m355_version.restype = i32
+    L.m355_init.argtypes = [i32]
+    L.m355_init.restype = i32
     L.m355_last_error.restype = ctypes.c_char_p
     L.m355_nf4_dequant.argtypes = [vp, vp, i64, i32, vp, vp]
     L.m355_repack_nf4.argtypes = [vp, vp, i32, i32, vp, vp, vp]
@@ -174,6 +176,14 @@ def prepare(fn) -> Prepared:
 
 def version() -> int:
     return int(load().m355_version())
+
+
+def init(device: Optional[int] = None) -> None:
+    """Per-device set-up (kernel attributes) ahead of the first call, so that the first call may already sit inside a
+    HIP graph capture.  m355_init."""
+    if device is None:
+        device = torch.cuda.current_device()
+    _check(load().m355_init(int(device)), "m355_init")
 
 
 def nf4_dequant(q: torch.Tensor, absmax: torch.Tensor, blocksize: int = 64, out: Optional[torch.Tensor] = None):

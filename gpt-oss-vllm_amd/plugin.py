@@ -35,6 +35,7 @@ except Exception:  # vLLM absent (or its import chain unusable): same surface, p
             pass
 
 QUANT_NAME = "mi355_nf4_moe"
+MAX_TOP_K_PRESIZE = 4   # top-k the configured max_tokens workspace is sized for (gpt-oss routes 4 experts per token)
 BLOCKSIZE = 64   # bitsandbytes' default NF4 block; the reference never passes another (streaming_unsloth_bnb.py:36-44)
 
 
@@ -88,6 +89,43 @@ def resolve_absmax_table(absmax: Optional[torch.Tensor], nested_absmax: Optional
         return codes.reshape(-1), nm * na.mean()
 
 
+def absmax_per_block(absmax: torch.Tensor, n_params: int) -> torch.Tensor:
+    """One fp32 scale per 64-weight block that reproduces, bit for bit, what the reference's dequantiser multiplies
+    each weight by for ANY count of absmax entries (patches/streaming_unsloth_bnb.py:197-218), so that the kernels'
+    fixed 64-weight blocks cover every branch:
+      * the count divides n_params: blocks of n_params / count weights (:197-202) -- each entry is repeated over its
+        64-weight pieces (blocks of 64, 128, 192, ...);
+      * a single entry (scalar absmax, or none -> ones(1), :173,216-218): that value for every block;
+      * any other count (:203-215): the block size the reference guesses (64 if the entries cover n_params / 64
+        blocks, else 128 if they cover n_params / 128, else 64), the entries it then uses, and 1.0 for the weights
+        beyond them, which it leaves unscaled.
+    Raises where a block of the reference is no whole number of 64-weight blocks (nothing a checkpoint with the
+    kernels' shapes produces)."""
+    a = absmax.detach().cpu().float().reshape(-1)
+    if n_params % BLOCKSIZE:
+        raise ValueError(f"{n_params} weights are no whole number of {BLOCKSIZE}-weight blocks")
+    nblk = n_params // BLOCKSIZE
+    cnt = a.numel()
+    if cnt == 1:
+        return a.expand(nblk).contiguous()
+    if n_params % cnt == 0:
+        bs = n_params // cnt
+        if bs % BLOCKSIZE:
+            raise ValueError(f"{cnt} absmax entries for {n_params} weights are blocks of {bs}: the kernels need "
+                             f"whole multiples of {BLOCKSIZE} (the reference's branch :197-202 at another block size)")
+        return a.repeat_interleave(bs // BLOCKSIZE)
+    bs = 64
+    for cand in (64, 128):                      # :205-209
+        if (n_params + cand - 1) // cand <= cnt:
+            bs = cand
+            break
+    used = min((n_params + bs - 1) // bs, cnt)  # :211-215: blocks beyond the entries stay unscaled
+    out = torch.ones(nblk, dtype=torch.float32)
+    piece = a[:used].repeat_interleave(bs // BLOCKSIZE)[:nblk]
+    out[:piece.numel()] = piece
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # "true_bnb" layout: a tensor read the way bitsandbytes itself reads it, not the way the reference's loader does
 # ---------------------------------------------------------------------------------------------
@@ -138,7 +176,8 @@ class Mi355Nf4MoEConfig(_QConfigBase):
     GATE_UP_ORDERS = ("concat", "interleaved")
     ABSMAX_STORAGE = ("auto", "fp32")
 
-    def __init__(self, layout: str = "reference", gate_up_order: str = "concat", absmax_storage: str = "auto"):
+    def __init__(self, layout: str = "reference", gate_up_order: str = "concat", absmax_storage: str = "auto",
+                 max_tokens: int = 0):
         """layout "reference": tensors are read as the reference's loader reads them (low nibble first, mean
         fallback for the nested scales, no offset) -- the parity contract.  "true_bnb": as bitsandbytes wrote
         them (high nibble first, one nested scale per 256 blocks, plus nested_offset)."""
@@ -150,6 +189,9 @@ class Mi355Nf4MoEConfig(_QConfigBase):
         if absmax_storage not in self.ABSMAX_STORAGE:
             raise ValueError(f"absmax_storage {absmax_storage!r}: expected one of {self.ABSMAX_STORAGE}")
         self.layout = layout
+        # tokens per forward the workspace is sized for when the weights are converted (vLLM: max_num_batched_tokens);
+        # 0 = grow on demand outside graph capture
+        self.max_tokens = int(max_tokens)
         # "auto": a layer whose experts all resolve to (code byte, 256-entry table) keeps the absmax that way on the
         # GPU (1 B instead of 4 B per 64 weights, same results bit for bit); "fp32": always one fp32 per block.
         self.absmax_storage = absmax_storage
@@ -182,7 +224,7 @@ class Mi355Nf4MoEConfig(_QConfigBase):
     def from_config(cls, config: Dict[str, Any]) -> "Mi355Nf4MoEConfig":
         config = config or {}
         return cls(layout=config.get("layout", "reference"), gate_up_order=config.get("gate_up_order", "concat"),
-                   absmax_storage=config.get("absmax_storage", "auto"))
+                   absmax_storage=config.get("absmax_storage", "auto"), max_tokens=int(config.get("max_tokens", 0)))
 
     def get_scaled_act_names(self) -> List[str]:
         return []
@@ -233,7 +275,12 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
 
         def param(shape, dtype):
             p = torch.nn.Parameter(torch.empty(shape, dtype=dtype, device=dev), requires_grad=False)
-            p.weight_loader = lambda *a, **k: self.weight_loader(layer, p, *a, **k)
+            # vLLM's model loaders call `param.weight_loader(param, loaded_weight, weight_name, shard_id=..,
+            # expert_id=..[, return_success=..])`: FusedMoE.weight_loader bound to its layer, the signature
+            # patches/patch_9_fusedmoe_unsloth.py:19 hooks
+            p.weight_loader = lambda param, loaded_weight, weight_name=None, shard_id=None, expert_id=None, \
+                return_success=False: self.weight_loader(layer, param, loaded_weight, weight_name, shard_id=shard_id,
+                                                         expert_id=expert_id, return_success=return_success)
             for key, val in extra_weight_attrs.items():
                 if key != "weight_loader":
                     setattr(p, key, val)
@@ -251,7 +298,8 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
         layer._m355_bias = {}         # "gate_up_proj_bias" | "down_proj_bias" -> fp16 [E][...] as loaded
         layer._m355_raw = {}          # (expert, "gate_up_projs"|"down_projs") -> {"weight"| suffix: tensor}
         layer._m355_ready = False
-        layer._m355_ws = {}
+        layer._m355_ws = None         # the forward's workspace: one buffer, grown to the largest batch seen
+        layer._m355_shard = None      # (expert_map identity, e_first) of vLLM expert parallelism, resolved once
 
     def weight_loader(self, layer, param, loaded_weight: torch.Tensor, weight_name: str, shard_id=None,
                       expert_id=None, return_success: bool = False):
@@ -259,6 +307,9 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
         names holding 'gate_up_projs' / 'down_projs' are parsed as
         model.layers.L.mlp.experts.<proj>.E.weight[.suffix]; the packed tensor is kept as loaded and converted
         later; returns `True if return_success else None`."""
+        if not isinstance(weight_name, str) or not isinstance(loaded_weight, torch.Tensor):
+            raise TypeError("weight_loader(param, loaded_weight, weight_name, shard_id, expert_id): loaded_weight must be "
+                            "a tensor and weight_name its checkpoint name")
         for bias_name in ("gate_up_proj_bias", "down_proj_bias"):     # fused [E][...] tensors of the gpt-oss checkpoint
             if weight_name.endswith(bias_name):
                 layer._m355_bias[bias_name] = loaded_weight
@@ -289,10 +340,12 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
         if dev.type != "cuda":
             raise lib.Mi355LibraryError("expert weights must live on the GPU before process_weights_after_loading")
         # byte absmax needs every expert of both matrices to resolve to (codes, table)
+        def as_codes(t):
+            ct = resolve_absmax_table(t.get("absmax"), t.get("nested_absmax"), t.get("nested_quant_map"))
+            return ct if ct is not None and "weight" in t and ct[0].numel() * (BLOCKSIZE // 2) == t["weight"].numel() else None
+
         use_codes = (self.quant_config.absmax_storage == "auto" and self.quant_config.layout == "reference"
-                     and len(layer._m355_raw) == 2 * E
-                     and all(resolve_absmax_table(t.get("absmax"), t.get("nested_absmax"), t.get("nested_quant_map")) is not None
-                             for t in layer._m355_raw.values()))
+                     and len(layer._m355_raw) == 2 * E and all(as_codes(t) is not None for t in layer._m355_raw.values()))
         if use_codes:
             layer._m355_codes = {"w13": torch.empty((E, 2 * FF * H // BLOCKSIZE), dtype=torch.uint8, device=dev),
                                  "w2": torch.empty((E, H * FF // BLOCKSIZE), dtype=torch.uint8, device=dev)}
@@ -323,7 +376,9 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
             else:
                 am = resolve_absmax(t.get("absmax"), t.get("nested_absmax"), t.get("nested_quant_map")).reshape(-1)
             if am.numel() * BLOCKSIZE != rows * cols:
-                raise ValueError(f"expert {e} {proj}: {am.numel()} absmax entries, the kernels need one per {BLOCKSIZE}")
+                if self.quant_config.layout != "reference":
+                    raise ValueError(f"expert {e} {proj}: {am.numel()} absmax entries, expected one per {BLOCKSIZE}")
+                am = absmax_per_block(am, rows * cols)     # the reference's other branches (:197-218), same bits
             interleaved = proj == "gate_up_projs" and self.quant_config.gate_up_order == "interleaved"
             qt, at = lib.repack_nf4(q.to(dev).contiguous(), am.float().to(dev).contiguous(), rows, cols,
                                     row_order=1 if interleaved else 0)
@@ -352,6 +407,10 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
             layer._m355_b2 = b2.to(device=dev, dtype=torch.float16).contiguous()
         layer._m355_bias = {}
         layer._m355_raw = {}
+        if self.quant_config.max_tokens > 0:
+            layer._m355_ws = torch.empty(max(256, lib.moe_workspace_bytes(self.quant_config.max_tokens, MAX_TOP_K_PRESIZE, H, FF, E)),
+                                         dtype=torch.uint8, device=dev)
+        lib.init(dev.index if dev.index is not None else torch.cuda.current_device())   # kernel attributes, before any graph capture
         layer._m355_ready = True
 
     # -- forward -------------------------------------------------------------------------------
@@ -380,18 +439,12 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
         if lg.dtype != torch.float16:
             lg = lg.to(torch.float16)
         ids, w = lib.topk_softmax(lg.contiguous(), top_k)
-        e_first = 0
-        if expert_map is not None:   # vLLM expert parallelism: map[global id] = local id or -1, contiguous shard
-            owned = torch.nonzero(expert_map >= 0).flatten()
-            e_first = int(owned[0].item()) if owned.numel() else 0
+        e_first = self._shard_first_expert(layer, expert_map)
         T = x2.shape[0]
         flags = lib.FLAG_FP16_COMBINE
         if expert_map is not None and global_num_experts > 0:     # a shard: see lib.kernel_choice_flags
             flags |= lib.kernel_choice_flags(T, top_k, global_num_experts)
-        ws = layer._m355_ws.get(T)
-        if ws is None:
-            ws = torch.empty(max(256, lib.moe_workspace_bytes(T, top_k, H, FF, E)), dtype=torch.uint8, device=x2.device)
-            layer._m355_ws = {T: ws}
+        ws = self._workspace(layer, T, top_k, x2.device)
         a13, a2 = layer.w13_absmax.data, layer.w2_absmax.data
         if getattr(layer, "_m355_codes", None) is not None:
             a13 = (layer._m355_codes["w13"], layer._m355_tables["w13"])
@@ -403,6 +456,50 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
         if in_dtype != torch.float16:
             out = out.to(in_dtype)
         return out.reshape(shape)
+
+
+    @staticmethod
+    def _shard_first_expert(layer, expert_map: Optional[torch.Tensor]) -> int:
+        """First global expert id of this rank's shard under vLLM expert parallelism (expert_map[global id] = local id
+        or -1, a contiguous shard).  Read back from the GPU once per map (the first eager forward, or
+        `set_expert_map`), never on the hot path and never under graph capture."""
+        if expert_map is None:
+            return 0
+        key = (id(expert_map), expert_map.data_ptr(), expert_map.numel())
+        cached = layer._m355_shard
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        if expert_map.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("expert_map seen for the first time during graph capture: run one eager forward first, "
+                               "or call method.set_expert_map(layer, expert_map) after loading")
+        owned = torch.nonzero(expert_map >= 0).flatten()
+        e_first = int(owned[0].item()) if owned.numel() else 0
+        E = layer._m355_dims[0]
+        if owned.numel() and (owned.numel() != E or int(owned[-1].item()) != e_first + E - 1):
+            raise ValueError(f"expert_map must map one contiguous range of {E} experts to this rank")
+        layer._m355_shard = (key, e_first, expert_map)    # (the map is kept alive so its identity cannot be reused)
+        return e_first
+
+    def set_expert_map(self, layer, expert_map: Optional[torch.Tensor]) -> int:
+        """Resolve the shard of `expert_map` ahead of the first forward (one device-to-host read, at load time)."""
+        layer._m355_shard = None
+        return self._shard_first_expert(layer, expert_map)
+
+    @staticmethod
+    def _workspace(layer, T: int, top_k: int, device) -> torch.Tensor:
+        """One workspace per layer, sized for the largest batch seen so far (or for the configured max_tokens): a smaller
+        batch carves its lists from the front of the same buffer, so continuous batching does not reallocate.  Under
+        graph capture a too-small buffer is not replaced (the capture's pool would own the new one): the call takes a
+        temporary from that pool instead."""
+        E, H, FF = layer._m355_dims
+        need = max(256, lib.moe_workspace_bytes(T, top_k, H, FF, E))
+        ws = layer._m355_ws
+        if ws is not None and ws.numel() >= need and ws.device == device:
+            return ws
+        fresh = torch.empty(need, dtype=torch.uint8, device=device)
+        if not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            layer._m355_ws = fresh
+        return fresh
 
 
 def cast_router_to_fp16(mlp_block) -> None:

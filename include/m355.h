@@ -54,6 +54,13 @@ typedef void* m355_stream_t; /* a hipStream_t (NULL = the default stream) */
 
 M355_API int m355_version(void);
 M355_API const char* m355_last_error(void);
+/*
+ * Per-device set-up ahead of time: the kernel attributes (dynamic-LDS limits) that the entry points otherwise set on
+ * their first call on a device.  Those calls cannot be captured, so a host that captures HIP graphs calls this once per
+ * device before its first capture; calling it again is free.  No counterpart in the reference, which runs vLLM with
+ * --enforce-eager (patches/gpt_oss_server.py:45).
+ */
+M355_API int m355_init(int device);
 
 /*
  * NF4 packed bytes -> fp16.  q holds n/2 bytes in checkpoint order (element 2i = low nibble of byte

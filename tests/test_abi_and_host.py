@@ -73,8 +73,15 @@ def test_weight_loader_hook_contract():
     name = "model.layers.7.mlp.experts.gate_up_projs.3.weight"
     assert m.weight_loader(layer, None, t, name, None, None, return_success=True) is True
     assert m.weight_loader(layer, None, t, name + ".absmax", None, None) is None
-    assert layer.w13_qweight.weight_loader(t, "model.layers.7.mlp.experts.down_projs.1.weight.nested_absmax", None, None,
-                                           return_success=True) is True
+    # the loader attached to a parameter is called the way vLLM's model loaders call FusedMoE.weight_loader:
+    # param.weight_loader(param, loaded_weight, weight_name, shard_id=.., expert_id=..[, return_success=..])  (patch_9:19)
+    p13 = layer.w13_qweight
+    assert p13.weight_loader(p13, t, "model.layers.7.mlp.experts.down_projs.1.weight.nested_absmax", shard_id="w2",
+                             expert_id=1, return_success=True) is True
+    assert p13.weight_loader(p13, t, "model.layers.7.mlp.experts.down_projs.1.weight", "w2", 1) is None
+    assert layer._m355_raw[(1, "down_projs")]["weight"] is t
+    with pytest.raises(TypeError):
+        p13.weight_loader(t, "model.layers.7.mlp.experts.down_projs.1.weight", None, None)     # param left out
     assert set(layer._m355_raw) == {(3, "gate_up_projs"), (1, "down_projs")}
     assert set(layer._m355_raw[(3, "gate_up_projs")]) == {"weight", "absmax"}
     assert "nested_absmax" in layer._m355_raw[(1, "down_projs")]
@@ -100,6 +107,56 @@ def test_host_absmax_resolution_equals_oracle(name, ref):
         codes, table = ct
         assert codes.dtype == torch.uint8 and tuple(table.shape) == (256,)
         assert np.array_equal(table[codes.long()].numpy().view(np.uint32).reshape(-1), want.view(np.uint32).reshape(-1))
+
+
+@pytest.mark.parametrize("name", ["down_nested_mean", "down_nested_scalar", "down_nested_elementwise", "down_absmax_f32",
+                                  "down_absmax_u8_plain", "down_no_absmax", "gate_up_absmax_single", "down_absmax_bs128",
+                                  "down_ragged_plus1", "down_ragged_bs128", "down_ragged_short", "down_nested_mean_u005",
+                                  "gate_up_nested_mean_u005"])
+def test_host_per_block_absmax_covers_every_reference_branch(name, ref):
+    """The product keeps one fp32 scale per 64 weights.  plugin.resolve_absmax + plugin.absmax_per_block must yield, for
+    every branch of the reference's dequantiser (other block sizes, a single absmax, none, counts that do not divide the
+    weight count: patches/streaming_unsloth_bnb.py:148-218), scales with which a plain 64-block dequantisation gives the
+    reference's output bit for bit (sha256 of the committed golden)."""
+    import hashlib
+    import json
+    from gpt_oss_vllm_amd import plugin
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "dequant_golden.json")))["cases"][name]
+    c = ref.golden_dequant_case(name)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    am = plugin.resolve_absmax(t(c["absmax"]), t(c["nested_absmax"]), t(c["nested_map"])).reshape(-1)
+    n = c["n_params"]
+    per64 = am if am.numel() * 64 == n else plugin.absmax_per_block(am, n)
+    assert per64.numel() * 64 == n and per64.dtype == torch.float32
+    out = ref.nf4_dequant_numpy(c["q"], n, per64.numpy()).view(np.uint16)       # divisible branch only
+    assert hashlib.sha256(out.tobytes()).hexdigest() == g["sha256"]
+
+
+def test_per_block_absmax_rejects_unrepresentable_blocks():
+    from gpt_oss_vllm_amd import plugin
+    with pytest.raises(ValueError, match="blocks of 32"):
+        plugin.absmax_per_block(torch.ones(8), 256)
+    with pytest.raises(ValueError):
+        plugin.absmax_per_block(torch.ones(3), 100)
+
+
+def test_checkpoint_missing_expert_policy(tmp_path):
+    """A matrix no shard holds: KeyError by default; with missing="zeros" an all-zero matrix, as the reference
+    substitutes zeros for a missing gate_up (patches/streaming_unsloth_bnb.py:261-264)."""
+    from safetensors.torch import save_file
+    from gpt_oss_vllm_amd import checkpoint
+    H, FF = 64, 64
+    k0 = checkpoint.expert_weight_key(0, 0, "gate_up")
+    shard = str(tmp_path / "s.safetensors")
+    save_file({k0: torch.zeros((2 * FF * H // 2, 1), dtype=torch.uint8), k0 + ".absmax": torch.ones(2 * FF * H // 64)}, shard)
+    with pytest.raises(KeyError):
+        list(checkpoint.iter_layer_tensors([shard], 0, 1))
+    got = dict(checkpoint.iter_layer_tensors([shard], 0, 2, missing="zeros", dims=(H, FF)))
+    kd = checkpoint.expert_weight_key(0, 1, "down")
+    assert got[kd].numel() == H * FF // 2 and (got[kd] == 0x77).all() and kd + ".absmax" not in got
+    assert got[checkpoint.expert_weight_key(0, 1, "gate_up")].numel() == FF * H
+    with pytest.raises(ValueError):
+        list(checkpoint.iter_layer_tensors([shard], 0, 1, missing="skip"))
 
 
 def test_checkpoint_reader_schema(tmp_path, ref):

@@ -59,6 +59,29 @@ def test_dequant_bit_exact_vs_reference_golden(name, ref, m355, cuda):
     assert np.array_equal(bits, want)
 
 
+@pytest.mark.parametrize("name", ["gate_up_nested_mean", "down_nested_mean", "down_nested_scalar", "down_nested_elementwise",
+                                  "down_absmax_f32", "down_absmax_u8_plain", "down_no_absmax", "gate_up_absmax_single",
+                                  "down_absmax_bs128", "down_ragged_plus1", "down_ragged_bs128", "down_ragged_short",
+                                  "down_nested_mean_u005", "gate_up_nested_mean_u005"])
+def test_dequant_product_path_vs_reference_golden(name, ref, m355, cuda):
+    """The scales come from the PRODUCT's host code (plugin.resolve_absmax: the reference's torch expressions, including
+    its fp32 mean of inexactly summing nested scales; plugin.absmax_per_block: every other branch of
+    patches/streaming_unsloth_bnb.py:197-218 expressed as one scale per 64 weights), the weights from the GPU kernel:
+    sha256 of the fp16 bits equals the reference's for every branch of its dequantiser."""
+    from gpt_oss_vllm_amd import plugin
+    gold = json.load(open(os.path.join(GOLD, "dequant_golden.json")))["cases"][name]
+    case = ref.golden_dequant_case(name)
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+    am = plugin.resolve_absmax(t(case["absmax"]), t(case["nested_absmax"]), t(case["nested_map"])).reshape(-1)
+    n = case["n_params"]
+    if am.numel() * 64 != n:
+        am = plugin.absmax_per_block(am, n)
+    out = m355.nf4_dequant(_to_dev(case["q"], cuda), am.float().contiguous().to(cuda), blocksize=64)
+    torch.cuda.synchronize()
+    bits = out.cpu().numpy().view(np.uint16)
+    assert hashlib.sha256(bits.tobytes()).hexdigest() == gold["sha256"]
+
+
 def test_dequant_rejects_bad_arguments(m355, cuda):
     q = torch.zeros(64, dtype=torch.uint8, device=cuda)
     a = torch.ones(2, dtype=torch.float32, device=cuda)
@@ -359,6 +382,16 @@ def test_plugin_path_end_to_end(ref, m355, cuda, tmp_path):
     layer = torch.nn.Module()
     method.create_weights(layer, E, H, FF, torch.float16, device=cuda)
     checkpoint.load_layer(method, layer, [shard], 2)
+    # the same layer filled the way vLLM's model loader fills it: param.weight_loader(param, tensor, name, shard_id, expert_id)
+    layer_v = torch.nn.Module()
+    method.create_weights(layer_v, E, H, FF, torch.float16, device=cuda)
+    for name, tensor in tensors.items():
+        proj = "w13_qweight" if "gate_up_projs" in name else "w2_qweight"
+        param = getattr(layer_v, proj)
+        assert param.weight_loader(param, tensor, name, shard_id="w1", expert_id=int(name.split(".")[6]), return_success=True) is True
+    method.process_weights_after_loading(layer_v)
+    assert torch.equal(layer_v.w13_qweight, layer.w13_qweight) and torch.equal(layer_v.w2_qweight, layer.w2_qweight)
+    assert torch.equal(layer_v._m355_codes["w13"], layer._m355_codes["w13"])
     x = ref.normal_f16(ref.stream_seed(9, 100), (T, H))
     lg = ref.normal_f16(ref.stream_seed(9, 101), (T, E), 1.5)
     out = method.apply(layer, _to_dev(x, cuda), _to_dev(lg, cuda), top_k=k, renormalize=True)
@@ -538,7 +571,10 @@ def test_moe_tile_kernel_prefill_size(ref, m355, cuda):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("T,E,k,bias,H,FF", [(1, 32, 4, False, 2880, 2880), (3, 32, 4, True, 2880, 2880),
                                              (8, 128, 4, False, 256, 192), (9, 32, 4, True, 256, 192),
-                                             (2, 256, 5, True, 256, 192), (40, 8, 2, False, 256, 192)])
+                                             (2, 256, 5, True, 256, 192), (40, 8, 2, False, 256, 192)]
+                         # every batch size of the fused-router form on the gpt-oss-20b routing shape (32 experts, top-4):
+                         # the router's picks and the per-expert pair masks share one LDS buffer in that launch
+                         + [(T, 32, 4, T % 2 == 0, 256, 192) for T in range(2, 9)] + [(5, 32, 4, False, 2880, 2880)])
 def test_router_and_experts_in_one_call(T, E, k, bias, H, FF, ref, m355, cuda):
     """m355_moe_nf4_forward_routed against router_topk followed by the forward: identical ids, weights and output
     (up to 8 tokens the gate_up launch computes the router itself with the router kernel's code; beyond, the call
@@ -636,3 +672,117 @@ def test_prepared_calls_repeat_the_wrappers(ref, m355, cuda):
         m355.prepare(lambda: m355.router_topk(x, wr, None, 64, ids=torch.empty((T, 64), dtype=torch.int32, device=cuda),
                                               w=torch.empty((T, 64), dtype=torch.float32, device=cuda)))
     assert m355.router_topk(x, wr, None, k)[0].shape == (T, k)
+
+
+# ------------------------------------------------------------------------------------------------
+def _small_plugin_layer(ref, cuda, E, H, FF, max_tokens=0, drop=()):
+    """A FusedMoE-like layer filled through the plug-in from synthetic checkpoint tensors; `drop` lists (expert, proj)
+    matrices that are withheld.  Returns (method, layer, oracle tensors)."""
+    from gpt_oss_vllm_amd import checkpoint, plugin
+    method = plugin.Mi355Nf4MoEConfig(max_tokens=max_tokens).get_quant_method(None, "model.layers.0.mlp.experts")
+    layer = torch.nn.Module()
+    method.create_weights(layer, E, H, FF, torch.float16, device=cuda)
+    lay = dict(w13_q=[], w13_absmax=[], w2_q=[], w2_absmax=[])
+    for e in range(E):
+        for proj, n, tag in (("gate_up", 2 * FF * H, "w13"), ("down", H * FF, "w2")):
+            q, a8, na, nm = ref.synth_expert_tensor(ref.stream_seed(19, e, n), n)
+            am = ref.resolve_absmax(a8, nm, na)
+            if (e, proj) in drop:
+                q, am = np.full_like(q, 0x77), np.ones_like(am)
+            else:
+                key = checkpoint.expert_weight_key(0, e, proj)
+                for sfx, val in (("", q.reshape(-1, 1)), (".absmax", a8), (".nested_absmax", na), (".nested_quant_map", nm)):
+                    method.weight_loader(layer, None, torch.from_numpy(val.copy()), key + sfx)
+            lay[tag + "_q"].append(q), lay[tag + "_absmax"].append(am)
+    return method, layer, {n: np.stack(v) for n, v in lay.items()}
+
+
+def test_plugin_apply_under_graph_capture_with_expert_map(ref, m355, cuda):
+    """FusedMoE.apply with vLLM's expert_map (expert parallelism) inside a HIP graph: the shard's first expert is read
+    back once (eagerly, or by set_expert_map), the workspace is the layer's one buffer whatever the batch size, and
+    nothing in apply() synchronises or allocates per call, so the capture succeeds and replays give the eager bits."""
+    E_loc, E_glob, H, FF, k = 4, 8, 256, 192, 2
+    method, layer, lay = _small_plugin_layer(ref, cuda, E_loc, H, FF, max_tokens=64)
+    method.process_weights_after_loading(layer)
+    emap = torch.full((E_glob,), -1, dtype=torch.int32, device=cuda)
+    emap[2:6] = torch.arange(4, dtype=torch.int32, device=cuda)
+    with pytest.raises(ValueError):
+        method.set_expert_map(layer, torch.tensor([0, -1, 1, 2, 3, -1, -1, -1], dtype=torch.int32, device=cuda))
+    assert method.set_expert_map(layer, emap) == 2
+    ws0 = layer._m355_ws
+    outs = {}
+    for T in (9, 33, 5):      # continuous batching: the batch size changes from step to step
+        x = _to_dev(ref.normal_f16(ref.stream_seed(29, T, 1), (T, H)), cuda)
+        lg = _to_dev(ref.normal_f16(ref.stream_seed(29, T, 2), (T, E_glob), 1.5), cuda)
+        eager = method.apply(layer, x, lg, top_k=k, renormalize=True, expert_map=emap, global_num_experts=E_glob)
+        assert layer._m355_ws is ws0                      # no reallocation
+        ids, w, _ = ref.router_topk(lg.cpu().numpy(), np.eye(E_glob, dtype=np.float16), None, k)
+        want = ref.moe_forward(x.cpu().numpy(), ids, w, **lay, E_local=E_loc, e_first=2, H=H, FF=FF)
+        _close(eager.cpu().numpy(), want)
+        outs[T] = (x, lg, eager)
+    x, lg, eager = outs[33]
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        method.apply(layer, x, lg, top_k=k, renormalize=True, expert_map=emap, global_num_experts=E_glob)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = method.apply(layer, x, lg, top_k=k, renormalize=True, expert_map=emap, global_num_experts=E_glob)
+    captured.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(captured, eager)
+    # a map never seen before, first met during capture: refused with a clear message instead of a device-to-host read
+    other = emap.clone()
+    g2 = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="set_expert_map"):
+        with torch.cuda.graph(g2):
+            method.apply(layer, x, lg, top_k=k, renormalize=True, expert_map=other, global_num_experts=E_glob)
+
+
+def test_plugin_missing_expert_as_zeros(ref, m355, cuda, tmp_path):
+    """checkpoint.load_layer(missing="zeros"): an expert whose gate_up matrix no shard holds contributes nothing, as with
+    the zeros the reference substitutes (patches/streaming_unsloth_bnb.py:261-264)."""
+    from safetensors.torch import save_file
+    from gpt_oss_vllm_amd import checkpoint, plugin
+    E, H, FF, k, T = 4, 256, 192, 2, 11
+    tensors, lay = {}, dict(w13_q=[], w13_absmax=[], w2_q=[], w2_absmax=[])
+    for e in range(E):
+        for proj, n, tag in (("gate_up", 2 * FF * H, "w13"), ("down", H * FF, "w2")):
+            q, a8, na, nm = ref.synth_expert_tensor(ref.stream_seed(39, e, n), n)
+            am = ref.resolve_absmax(a8, nm, na)
+            if (e, proj) == (1, "gate_up"):
+                q, am = np.full_like(q, 0x77), np.ones_like(am)
+            else:
+                key = checkpoint.expert_weight_key(5, e, proj)
+                tensors.update({key: torch.from_numpy(q.copy()).reshape(-1, 1), key + ".absmax": torch.from_numpy(a8.copy()),
+                                key + ".nested_absmax": torch.from_numpy(na.copy()),
+                                key + ".nested_quant_map": torch.from_numpy(nm.copy())})
+            lay[tag + "_q"].append(q), lay[tag + "_absmax"].append(am)
+    lay = {n: np.stack(v) for n, v in lay.items()}
+    shard = str(tmp_path / "m.safetensors")
+    save_file(tensors, shard)
+    method = plugin.Mi355Nf4MoEConfig().get_quant_method(None, "model.layers.5.mlp.experts")
+    layer = torch.nn.Module()
+    method.create_weights(layer, E, H, FF, torch.float16, device=cuda)
+    with pytest.raises(KeyError):
+        checkpoint.load_layer(method, layer, [shard], 5)
+    layer = torch.nn.Module()
+    method.create_weights(layer, E, H, FF, torch.float16, device=cuda)
+    checkpoint.load_layer(method, layer, [shard], 5, missing="zeros")
+    x = ref.normal_f16(ref.stream_seed(39, 100), (T, H))
+    lg = ref.normal_f16(ref.stream_seed(39, 101), (T, E), 1.5)
+    out = method.apply(layer, _to_dev(x, cuda), _to_dev(lg, cuda), top_k=k, renormalize=True)
+    ids, w, _ = ref.router_topk(lg, np.eye(E, dtype=np.float16), None, k)
+    assert (ids == 1).any()
+    want = ref.moe_forward(x, ids, w, **lay, E_local=E, H=H, FF=FF)
+    _close(out.cpu().numpy(), want)
+
+
+def test_init_before_first_call_allows_immediate_capture(ref, m355, cuda):
+    m355.init(0)
+    m355.init()      # idempotent
+    with pytest.raises(m355.Mi355LibraryError):
+        m355.init(10 ** 6)

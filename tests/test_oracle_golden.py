@@ -38,6 +38,31 @@ def test_dequant_bit_exact_vs_reference(name, ref):
     assert np.array_equal(out[pos], np.array(g["sample_bits"], dtype=np.uint16))
 
 
+@pytest.mark.parametrize("name", ["down_nested_mean_u005", "gate_up_nested_mean_u005"])
+def test_dequant_inexact_mean_vs_reference(name, ref):
+    """nested_absmax ~ U(0, 0.05): the fp32 sum behind the reference's `nested_absmax.mean()`
+    (patches/streaming_unsloth_bnb.py:171) depends on the order of the additions.  The C restatement sums in double, which
+    is a correctly rounded mean but not torch's (2 ulp apart on the 1013 scales of the gate_up case, equal on the 507 of
+    the down case); handed torch's mean (the reference's own expression, also what
+    the product's host code evaluates) it reproduces the reference's output bit for bit."""
+    import torch
+    g = _gold()["cases"][name]
+    case = ref.golden_dequant_case(name)
+    na = case["nested_absmax"]
+    torch_mean = np.float32(torch.from_numpy(na.copy()).mean().item())
+    double_mean = np.float32(na.astype(np.float64).mean())
+    assert abs(float(torch_mean) - float(double_mean)) <= 4 * float(np.spacing(double_mean))  # a few ulp apart at most
+    if name.startswith("gate_up"):   # the case exists because the two differ: with the double mean the bits are not the reference's
+        assert torch_mean != double_mean
+        own = ref.nf4_dequant(case["q"], case["n_params"], ref.resolve_absmax(case["absmax"], case["nested_map"], na))
+        assert hashlib.sha256(own.view(np.uint16).tobytes()).hexdigest() != g["sha256"]
+    a = ref.resolve_absmax(case["absmax"], case["nested_map"], na, mean_override=torch_mean)
+    out = ref.nf4_dequant(case["q"], case["n_params"], a).view(np.uint16)
+    assert hashlib.sha256(out.tobytes()).hexdigest() == g["sha256"]
+    pos = np.array(g["sample_pos"])
+    assert np.array_equal(out[pos], np.array(g["sample_bits"], dtype=np.uint16))
+
+
 @pytest.mark.parametrize("name", ["down_nested_mean", "down_ragged_short", "down_absmax_bs128", "gate_up_absmax_single"])
 def test_numpy_twin_equals_c(name, ref):
     case = ref.golden_dequant_case(name)
