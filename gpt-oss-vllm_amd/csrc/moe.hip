@@ -869,8 +869,13 @@ static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, c
     }
     if (sp.bias || sp.act_mode != M355_ACT_SILU_CONCAT || wam8)
         return fail(-5, "m355_moe_nf4_forward: biases, swiglu-oai and byte absmax need K <= %d (K = %d)", 64 * MOE_KPARTS * MOE_CHUNK, K);
-    moe_gemm_kernel<MODE><<<dim3((NP + MOE_PAIRS - 1) / MOE_PAIRS, slots), dim3(MOE_THREADS), gemm_lds_bytes(K, mt_rows), st>>>(
-        xin, wq, wam, ws.n_active, ws.offsets, ws.active, ws.sorted, K, R, k_top, mt_rows, outp);
+    // this kernel walks an expert's tokens by itself (it reads the offsets, not the token-tile lists), so it may take fewer
+    // tokens per pass than the routing step's tiles: as many activation rows as fit in LDS beside the tables
+    const int fit = (160 * 1024 - LUT_BYTES - RED_BYTES) / (K * 2 + XS_PAD);
+    const int mt_gen = mt_rows < fit ? mt_rows : fit;
+    if (mt_gen < 1) return fail(-2, "m355_moe_nf4_forward: K = %d is too large for the LDS activation tile", K);
+    moe_gemm_kernel<MODE><<<dim3((NP + MOE_PAIRS - 1) / MOE_PAIRS, slots), dim3(MOE_THREADS), gemm_lds_bytes(K, mt_gen), st>>>(
+        xin, wq, wam, ws.n_active, ws.offsets, ws.active, ws.sorted, K, R, k_top, mt_gen, outp);
     M355_LAUNCH_CHECK("moe_gemm_kernel");
     return 0;
 }
@@ -955,9 +960,6 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
     int dev = 0, cus = 0;
     if (int rc = hip_status(hipGetDevice(&dev), "hipGetDevice")) return rc;
     if (int rc = device_setup(dev, &cus)) return rc;
-    const bool general_kernel = !tiled && (H / 64 > MOE_KPARTS * MOE_CHUNK || FF / 64 > MOE_KPARTS * MOE_CHUNK);   // (stages activations in LDS)
-    if (general_kernel && (gemm_lds_bytes(H, mt_rows) > 160 * 1024 || gemm_lds_bytes(FF, mt_rows) > 160 * 1024))
-        return fail(-2, "m355_moe_nf4_forward: H or FF too large for the LDS activation tile");
 
     // gate_up buckets the pairs itself when it can; the routing kernel runs when it cannot, or when gate_up is skipped
     const bool inline_route = !tiled && !wide && can_route_inline(P, E_local, H) && !(flags & M355_FLAG_SKIP_GATE_UP);
