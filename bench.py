@@ -35,34 +35,57 @@ MFMA_PEAK_TFLOPS = 2500.0    # dense fp16
 GATE_UP_FLOPS_PER_PAIR = 2 * 2 * FF * H   # one (token, expert) pair through W13
 
 
-def profiled_mfma_busy():
-    """Fraction of the launch's cycles in which the matrix cores were busy, for the tile kernel's gate_up launch, from
-    the newest committed counter profile (collected in separate rocprofv3 --pmc passes, not in this run)."""
+STAMPED_SOURCES = ("gpt-oss-vllm_amd/csrc/moe.hip", "gpt-oss-vllm_amd/csrc/moe_tile.hip", "gpt-oss-vllm_amd/csrc/moe_shared.h")
+
+
+def git_blob_hash(path):
+    """The hash `git hash-object` gives the file (sha1 over "blob <size>\\0" + bytes): computed here because the GPU box
+    receives the tree without .git."""
+    import hashlib
+    with open(path, "rb") as f:
+        data = f.read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def source_stamps():
+    return {rel: git_blob_hash(os.path.join(ROOT, rel)) for rel in STAMPED_SOURCES}
+
+
+def _newest_counter_profile():
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
         return None, None
     try:
         with open(files[-1]) as f:
-            d = json.load(f)
-        return d.get("tile_gate_up_mfma_busy_frac"), os.path.basename(files[-1])
+            return json.load(f), os.path.basename(files[-1])
     except (OSError, ValueError):
         return None, None
+
+
+def counters_stale(profile):
+    """True when the kernel sources differ from the ones the counter profile was collected on (their git blob hashes are
+    stamped into the profile by profiles/summarize.py), None when the profile carries no stamps."""
+    stamps = (profile or {}).get("source_blobs")
+    if not stamps:
+        return None
+    now = source_stamps()
+    return any(now.get(rel) != h for rel, h in stamps.items())
+
+
+def profiled_mfma_busy():
+    """Fraction of the launch's cycles in which the matrix cores were busy, for the tile kernel's gate_up launch, from
+    the newest committed counter profile (collected in separate rocprofv3 --pmc passes, not in this run)."""
+    d, name = _newest_counter_profile()
+    return (None, None) if d is None else (d.get("tile_gate_up_mfma_busy_frac"), name)
 
 
 def profiled_traffic():
     """HBM bytes per gate_up launch from the newest committed counter profile (profiles/rNN_traffic.json, written by
-    profiles/summarize.py from separate rocprofv3 --pmc passes): counters cannot be read from inside this run."""
-    import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
-    if not files:
-        return None, None
-    try:
-        with open(files[-1]) as f:
-            d = json.load(f)
-        return d.get("gate_up_hbm_bytes_per_launch"), os.path.basename(files[-1])
-    except (OSError, ValueError):
-        return None, None
+    profiles/summarize.py from separate rocprofv3 --pmc passes): counters cannot be read from inside this run.
+    Returns (bytes, file name, stale)."""
+    d, name = _newest_counter_profile()
+    return (None, None, None) if d is None else (d.get("gate_up_hbm_bytes_per_launch"), name, counters_stale(d))
 
 
 class DecodeStep:
@@ -186,25 +209,35 @@ class DecodeStep:
         return [int(torch.unique(lay["ids"]).numel()) for lay in self.L]
 
 
-def timed(stepper, steps, warmup, world):
+def timed(stepper, steps, warmup, world, windows=1):
+    """`windows` timed regions of exactly `steps` steps each, after `warmup` untimed steps; every region is bracketed by a
+    barrier + synchronize on both sides and is the maximum over the ranks.  Returns the list of region durations."""
     import torch.distributed as dist
     for _ in range(warmup):
         stepper.step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        stepper.step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=stepper.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    return dt
+    out = []
+    for _ in range(windows):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            stepper.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=stepper.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        out.append(dt)
+    return out
+
+
+def median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
 
 
 def roofline_gate_up(stepper, reps=5):
@@ -481,9 +514,36 @@ def prefill_leg(lib, main_step, device, tokens, reps=3):
                      "achieved": fl_gu / t_gu / 1e12, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": fl_gu / t_gu / 1e12 / MFMA_PEAK_TFLOPS, "avg_us": t_gu * 1e6, "flops_per_launch": fl_gu,
                      "mfma_busy_frac_counters": profiled_mfma_busy()[0], "mfma_busy_source": profiled_mfma_busy()[1],
+                     "mfma_busy_stale": counters_stale(_newest_counter_profile()[0]),
                      "down_kernel": {"achieved": fl_gu / 2 / t_dn / 1e12, "avg_us": t_dn * 1e6,
                                      "frac": fl_gu / 2 / t_dn / 1e12 / MFMA_PEAK_TFLOPS}},
     }
+
+
+def dequant_leg(lib, main_step, device, reps=5):
+    """The standalone NF4 -> fp16 dequantiser (m355_nf4_dequant, what the reference's dequant_unsloth_expert_cpu computes)
+    over the packed bytes of one layer's experts: GB/s against the algorithmic 0.515625 B read + 2 B written per
+    weight (the kernel is handed fp32 absmax, 0.0625 B per weight instead of 0.015625; priced at the algorithmic figure)."""
+    lay = main_step.L[0]
+    q = torch.cat([lay["w13_q"].reshape(-1), lay["w2_q"].reshape(-1)])
+    n = q.numel() * 2
+    g = torch.Generator(device=device)
+    g.manual_seed(64)
+    am = torch.rand(n // 64, dtype=torch.float32, device=device, generator=g) * 0.03
+    out = torch.empty(n, dtype=torch.float16, device=device)
+    lib.nf4_dequant(q, am, 64, out=out)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        lib.nf4_dequant(q, am, 64, out=out)
+    b.record()
+    b.synchronize()
+    t = a.elapsed_time(b) * 1e-3 / reps
+    alg = n * 2.515625
+    return {"kernel": "nf4_dequant_kernel", "weights": n, "avg_us": t * 1e6, "algorithmic_bytes": alg,
+            "achieved": alg / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / t / 1e9 / HBM_PEAK_GBS,
+            "what": f"one layer's {lay['w13_q'].shape[0]} experts (gate_up + down), checkpoint-order bytes, fp32 absmax per 64"}
 
 
 def load_leg(device):
@@ -525,6 +585,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=5,
+                    help="timed regions of --steps steps each; the reported figure is their median")
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--ctx", type=int, default=256)
     ap.add_argument("--shape", choices=("20b", "120b"), default="20b",
@@ -543,7 +605,10 @@ def main():
     ap.add_argument("--prefill-tokens", type=int, default=8192,
                     help="also run a prefill-sized batch through the MoE path (0 = skip): the MFMA-bound leg")
     ap.add_argument("--load-leg", action="store_true", help="also time checkpoint -> GPU weights for one layer")
-    ap.add_argument("--full-layer-leg", action="store_true", help="also time the whole decoder stack (bs = --batch-per-gpu and 1)")
+    ap.add_argument("--full-layer-leg", action="store_true",
+                    help="also time the whole decoder stack over one --prefill-tokens prompt (the decode form of that leg is in the default line)")
+    ap.add_argument("--no-full-layer", action="store_true", help="skip the whole-decoder-stack decode leg")
+    ap.add_argument("--no-dequant-leg", action="store_true")
     a = ap.parse_args()
     global E, LAYERS
     if a.shape == "120b":
@@ -589,12 +654,15 @@ def main():
             stepper.prepare()
 
     capture(main_step)
-    dt = timed(main_step, a.steps, a.warmup, world)
+    dts = timed(main_step, a.steps, a.warmup, world, windows=a.windows)
+    dt = median(dts)      # the headline figure is the median window; every window is in `windows_ms_per_step`
     tokens = a.batch_per_gpu * world
     result = {
         "metric": f"decode tokens/sec gpt-oss-{a.shape} NF4 (hot path: paged-attn + router + fused NF4 MoE, {a.layers} layers)",
         "value": tokens * a.steps / dt, "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / a.steps * 1e3, "windows": a.windows,
+        "windows_ms_per_step": [round(d / a.steps * 1e3, 4) for d in dts],
+        "spread_frac": (max(dts) - min(dts)) / dt, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16", "data": "synthetic",
         "config": {
             "workload": (f"gpt-oss-{a.shape}-shaped NF4 decode, bs={a.batch_per_gpu} per GPU (global {tokens}), ctx {a.ctx}, "
@@ -604,6 +672,8 @@ def main():
             "parallelism": "single" if world == 1 else f"ep{world}+dp{world}", "hip_graph": use_graph,
             "host_calls": "hip graph" if use_graph else ("plain" if a.eager or not sharded else "prepared"),
             "absmax_storage": a.absmax,
+            "attention_parity": "unpinned: the reference's decode attention lives in flash-attn 2 and it holds no fixture; "
+                                "the kernel is checked against an fp32 softmax restatement and transformers' eager attention",
         },
     }
 
@@ -625,8 +695,10 @@ def main():
         bs1.run_eager()
         torch.cuda.synchronize()
         capture(bs1)
-        dt1 = timed(bs1, a.steps, a.warmup, world)
+        dts1 = timed(bs1, a.steps, a.warmup, world, windows=a.windows)
+        dt1 = median(dts1)
         out = {"value": world * a.steps / dt1, "unit": "tokens/s", "ms_per_step": dt1 / a.steps * 1e3,
+               "windows_ms_per_step": [round(d / a.steps * 1e3, 4) for d in dts1],
                "workload": f"bs=1 per GPU (global {world}), ctx {a.ctx}: BASELINE configs[1]" if world == 1
                else f"bs=1 per GPU (global {world}), ctx {a.ctx}, EP{world}"}
         if rank == 0 and world == 1 and not a.no_roofline:
@@ -639,12 +711,13 @@ def main():
 
     def roofline_leg():
         r, active = roofline_gate_up(main_step)
-        traffic, traffic_src = profiled_traffic()
+        traffic, traffic_src, stale = profiled_traffic()
         tflops = a.batch_per_gpu * TOPK * GATE_UP_FLOPS_PER_PAIR / (r["gate_up"]["avg_us"] * 1e-6) / 1e12
         return {
             "bound": "hbm", "kernel": "moe_gemm_stream_kernel<gate_up> (NF4 dequant fused into the grouped GEMM)",
             "achieved": r["gate_up"]["gbs"], "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": r["gate_up"]["gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_stale": stale,
             "avg_us": r["gate_up"]["avg_us"], "algorithmic_bytes_per_launch": r["gate_up"]["bytes"],
             "mean_active_experts": sum(active) / len(active),
             "down_kernel": {"achieved": r["down"]["gbs"], "avg_us": r["down"]["avg_us"],
@@ -664,7 +737,9 @@ def main():
         attempt("cpu_baseline", cpu_baseline)
     if single and a.full_layer_leg and a.prefill_tokens > 0:
         attempt("full_decoder_stack_prompt", lambda: full_layer_prompt_leg(lib, main_step, a.prefill_tokens, a.layers, device))
-    if single and a.full_layer_leg:
+    if single and not a.no_dequant_leg:
+        attempt("dequant", lambda: dequant_leg(lib, main_step, device))
+    if single and not a.no_full_layer:
         attempt("full_decoder_stack", lambda: [full_layer_leg(lib, main_step, b, a.ctx, a.layers, device, a.steps, a.warmup)
                                                for b in (a.batch_per_gpu, 1)])
     if single and a.load_leg:

@@ -85,12 +85,26 @@ if tile_pmc:
                 mfma_busy[kern] = sum(busy) / len(busy) / (1024 * cyc)
                 out.write(f"\n{kern}: matrix cores busy {sum(busy) / len(busy) / (1024 * cyc):.3f} of the cycles of the launch "
                           f"(SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 = {cyc:.4g} cycles)).\n")
+import hashlib
+import os
+
+
+def blob(path):
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+stamped = ("gpt-oss-vllm_amd/csrc/moe.hip", "gpt-oss-vllm_amd/csrc/moe_tile.hip", "gpt-oss-vllm_amd/csrc/moe_shared.h")
+# the sources the counters were taken on travel with the run (profile_round.sh copies their hashes); fall back to the tree
+stamp_file = f"{src}/source_blobs.json"
+source_blobs = json.load(open(stamp_file)) if os.path.exists(stamp_file) else {p: blob(p) for p in stamped}
 rd = pmc.get(("gate_up", "TCC_EA0_RDREQ_sum"))
 rd_down = pmc.get(("down", "TCC_EA0_RDREQ_sum"))
 if rd:
     with open(f"profiles/{tag}_traffic.json", "w") as out:
         json.dump({"gate_up_hbm_bytes_per_launch": sum(rd) / len(rd) * 128,
                    "down_hbm_bytes_per_launch": (sum(rd_down) / len(rd_down) * 128) if rd_down else None,
+                   "source_blobs": source_blobs,
                    "source": "TCC_EA0_RDREQ_sum x 128 B, rocprofv3 --pmc pass over scratch/prof_moe.py (bs=32)",
                    "tile_gate_up_mfma_busy_frac": mfma_busy.get("gate_up"), "tile_down_mfma_busy_frac": mfma_busy.get("down"),
                    "mfma_busy_source": "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), rocprofv3 --pmc passes "

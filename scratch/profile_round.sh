@@ -4,6 +4,8 @@
 tag=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_$tag
+mkdir -p gpurun_out/prof_$tag
+python3 -c "import json, bench; json.dump(bench.source_stamps(), open('gpurun_out/prof_$tag/source_blobs.json', 'w'), indent=1)"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag/trace -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bs1 > gpurun_out/prof_${tag}_bench.log 2>&1 || { tail -5 gpurun_out/prof_${tag}_bench.log; exit 1; }
 grep '^{' gpurun_out/prof_${tag}_bench.log > gpurun_out/prof_$tag/bench_line.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag/trace_bs1 -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bs1 --batch-per-gpu 1 > gpurun_out/prof_${tag}_bench_bs1.log 2>&1 || { tail -5 gpurun_out/prof_${tag}_bench_bs1.log; exit 1; }
