@@ -29,6 +29,7 @@ extern "C" int m355_init(int device) {
         if (int rc = m355::hip_status(hipSetDevice(device), "hipSetDevice")) return rc;
     int rc = m355::moe_device_init(device);
     if (!rc) rc = m355::dense_tile_device_init(device);
+    if (!rc) rc = m355::moe_static_device_init(device);
     if (prev != device) {
         const int rc2 = m355::hip_status(hipSetDevice(prev), "hipSetDevice");
         if (!rc) rc = rc2;

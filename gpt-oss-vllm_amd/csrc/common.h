@@ -60,6 +60,7 @@ struct PerDeviceOnce {
 // current.  m355_init runs them all so that nothing is left to a first call inside a graph capture.
 int moe_device_init(int dev);
 int dense_tile_device_init(int dev);
+int moe_static_device_init(int dev);
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 

@@ -28,6 +28,7 @@ EXPORTS = (
     "m355_add_rmsnorm", "m355_rope_kv_write", "m355_linear_f16", "m355_paged_attn_decode_ex",
     "m355_repack_nf4_ex", "m355_moe_nf4_forward_ex", "m355_moe_nf4_forward_q8", "m355_repack_absmax_u8",
     "m355_moe_nf4_forward_routed", "m355_attn_prefill", "m355_moe_combine_add_rmsnorm", "m355_init",
+    "m355_moe_nf4_forward_static",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -59,6 +60,9 @@ def load() -> ctypes.CDLL:
     L.m355_moe_nf4_forward_ex.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
                                           vp, vp, f32, f32, vp, sz, vp, vp]
     L.m355_moe_nf4_forward_ex.restype = i32
+    L.m355_moe_nf4_forward_static.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
+                                              vp, vp, f32, f32, vp, vp]
+    L.m355_moe_nf4_forward_static.restype = i32
     L.m355_moe_nf4_forward_q8.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
                                           vp, vp, f32, f32, vp, sz, vp, vp]
     L.m355_moe_nf4_forward_q8.restype = i32
@@ -298,6 +302,26 @@ def moe_nf4_forward(x, ids, w, w13_q, w13_absmax, w2_q, w2_absmax, *, E_local: i
         None if b2 is None else _dev(b2, torch.float16, "b2"), float(alpha), float(limit),
         _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
         _dev(out, torch.float16, "out"), _stream()), "m355_moe_nf4_forward")
+    return out
+
+
+STATIC_WORKSPACE_BYTES = 8 << 20   # M355_STATIC_WORKSPACE_BYTES of include/m355.h
+
+
+def moe_nf4_forward_static(x, ids, w, w13_q, w13_absmax, w2_q, w2_absmax, *, E_local: int, e_first: int, H: int, FF: int,
+                           out: torch.Tensor, act_mode: int = ACT_SILU_CONCAT, flags: int = FLAG_FP16_COMBINE,
+                           b13: Optional[torch.Tensor] = None, b2: Optional[torch.Tensor] = None, alpha: float = 1.702,
+                           limit: float = 7.0):
+    """moe_nf4_forward (fp32 absmax) with the workspace inside the library: nothing is allocated, here or there, so `out`
+    must be given.  Shapes beyond the library's static workspace raise.  m355_moe_nf4_forward_static."""
+    T, k = ids.shape
+    _check(load().m355_moe_nf4_forward_static(
+        _dev(x, torch.float16, "x"), T, _dev(ids, torch.int32, "ids"), _dev(w, torch.float32, "w"), k,
+        _dev(w13_q, torch.uint8, "w13_q"), _dev(w13_absmax, torch.float32, "w13_absmax"),
+        _dev(w2_q, torch.uint8, "w2_q"), _dev(w2_absmax, torch.float32, "w2_absmax"), E_local, e_first, H, FF,
+        act_mode, flags, None if b13 is None else _dev(b13, torch.float16, "b13"),
+        None if b2 is None else _dev(b2, torch.float16, "b2"), float(alpha), float(limit),
+        _dev(out, torch.float16, "out"), _stream()), "m355_moe_nf4_forward_static")
     return out
 
 

@@ -130,6 +130,23 @@ M355_API int m355_moe_nf4_forward_ex(const void* x_f16, int T, const int32_t* id
                                      const float* w2_absmax, int E_local, int e_first, int H, int FF, int act_mode,
                                      int flags, const void* b13_f16, const void* b2_f16, float alpha, float limit,
                                      void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream);
+/*
+ * m355_moe_nf4_forward_ex for callers that cannot allocate and have no workspace to pass: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  The workspace lives in a
+ * device array inside the library, M355_STATIC_WORKSPACE_BYTES per GPU, held from the library's load to the end of the
+ * process; the call allocates and frees nothing.  Same arguments and results (bit for bit) as m355_moe_nf4_forward_ex
+ * without `workspace` / `ws_bytes`.  Shapes whose m355_moe_workspace_bytes(T, k, H, FF, E_local) exceeds the array are
+ * refused with -6 (gpt-oss shapes: up to 181 tokens at top-4).  All calls on one GPU share that GPU's array: two calls that
+ * overlap on one GPU (different streams, or different host threads) race; calls on one stream are ordered.  The array's
+ * address is looked up once per device, by m355_init or by the first call on the device (which therefore must not sit
+ * inside a graph capture unless m355_init ran).
+ */
+#define M355_STATIC_WORKSPACE_BYTES (8u << 20)
+M355_API int m355_moe_nf4_forward_static(const void* x_f16, int T, const int32_t* ids, const float* w, int k,
+                                         const uint8_t* w13_q, const float* w13_absmax, const uint8_t* w2_q,
+                                         const float* w2_absmax, int E_local, int e_first, int H, int FF, int act_mode,
+                                         int flags, const void* b13_f16, const void* b2_f16, float alpha, float limit,
+                                         void* out_f16, m355_stream_t stream);
 /* The same with the absmax kept as the checkpoint stores it: one code byte per 64-weight block (tile order of
  * m355_repack_absmax_u8) and, per expert, a 256-entry fp32 table that maps a code to its absmax -- the
  * `nested_quant_map[code] * scale` of patches/streaming_unsloth_bnb.py:150-171 with the scalar (the single
