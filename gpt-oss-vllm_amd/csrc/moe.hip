@@ -34,6 +34,18 @@ constexpr int RED_BYTES = MOE_PAIRS * (MOE_KPARTS - 1) * 64 * 8 * 4;
 constexpr int XS_PAD = 16;        // bytes of padding per staged activation row
 constexpr int MOE_MAX_MT = 16;
 
+#ifdef M355_EXP_STAMPS   /* diagnostic build: cycle stamps of waves 0 and 4 of every workgroup of the streaming kernel */
+__device__ unsigned long long m355_dbg[512 * 2 * 128];
+#define M355_STAMP()                                                                                          \
+    if ((wave & 3) == 0 && dbg_n < 124) {                                                                     \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                           \
+        if (lane == 0) m355_dbg[((size_t)(blockIdx.x & 511) * 2 + (wave >> 2)) * 128 + 4 + dbg_n] = t_;          \
+        dbg_n++;                                                                                              \
+    }
+#else
+#define M355_STAMP()
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Routing: one workgroup buckets the pairs by local expert.
 // ------------------------------------------------------------------------------------------------
@@ -270,6 +282,9 @@ __global__ __launch_bounds__(MOE_THREADS) void moe_gemm_kernel(const half_t* __r
             M355_BLOCK(0) M355_BLOCK(1) M355_BLOCK(2) M355_BLOCK(3) M355_BLOCK(4) M355_BLOCK(5)
             M355_BLOCK(6) M355_BLOCK(7) M355_BLOCK(8) M355_BLOCK(9) M355_BLOCK(10) M355_BLOCK(11)
 #undef M355_BLOCK
+#undef M355_FIRST_FETCH
+#undef M355_STAGGER
+#undef M355_SCHED_FENCE
         }
 
         // sum the K-parts: parts 1..3 park their tiles in LDS, part 0 adds them and writes the result
@@ -357,6 +372,36 @@ __device__ __forceinline__ void gemm_epilogue(float4_t accA, float4_t accB, half
         for (int r = 0; r < 4; r++) { ya[r] = (half_t)accA[r]; yb[r] = (half_t)accB[r]; }
         *reinterpret_cast<half4_t*>(outp + orow * R + 16 * p + 4 * g) = ya;
         *reinterpret_cast<half4_t*>(outp + orow * R + 16 * (p + NP) + 4 * g) = yb;
+    }
+}
+
+// One output element of an item: row 16p + `row` of the first tile (sumA) and the same row of the partner tile (sumB) for
+// token row `orow`: h = act(gate, up) (MODE 0) or the two y values (MODE 1), expert e.  Same arithmetic, element by
+// element, as gemm_epilogue.
+template <int MODE>
+__device__ __forceinline__ void gemm_epilogue1(float sumA, float sumB, half_t* __restrict__ outp, int64_t orow, int R, int NP,
+                                               int p, int row, int e, const StageParams& sp) {
+    if (sp.bias) {
+        sumA += (float)sp.bias[(int64_t)e * R + 16 * p + row];
+        sumB += (float)sp.bias[(int64_t)e * R + 16 * (p + NP) + row];
+    }
+    if (MODE == 0) {
+        half_t hv;
+        if (sp.act_mode == M355_ACT_SWIGLU_OAI) {
+            const float gt = fminf((float)(half_t)sumA, sp.limit);   // gate and up leave the GEMM as fp16
+            const float up = fminf(fmaxf((float)(half_t)sumB, -sp.limit), sp.limit);
+            const float glu = gt / (1.0f + expf(-sp.alpha * gt));
+            hv = (half_t)((up + 1.0f) * glu);
+        } else {
+            const float gt = (float)(half_t)sumA;   // gate and up leave the GEMM as fp16
+            const float up = (float)(half_t)sumB;
+            const half_t sg = (half_t)(gt / (1.0f + expf(-gt)));
+            hv = (half_t)((float)sg * up);
+        }
+        outp[orow * (R / 2) + 16 * p + row] = hv;
+    } else {
+        outp[orow * R + 16 * p + row] = (half_t)sumA;
+        outp[orow * R + 16 * (p + NP) + row] = (half_t)sumB;
     }
 }
 
@@ -458,24 +503,30 @@ __device__ __forceinline__ void inline_route(const RouteIO& rio, int my_e, int m
     __syncthreads();   // the lists are complete, and the mask area is free again
 }
 
-// 256 x 32 code table with 256-byte rows: entry (byte, replica) = half2(code[byte & 15], code[byte >> 4]).  The 16
-// codes come from immediates (a select chain in 16 threads, parked in `park`), not from memory.
-__device__ __forceinline__ void build_lutp(uint32_t* lut, unsigned char* park, int tid, int threads) {
-    half_t* codes = reinterpret_cast<half_t*>(park);
-    if (tid < 16) {
-        const float tab[16] = M355_NF4_TABLE;
-        float c = 0.f;
+// 256 x 32 code table with 256-byte rows: entry (byte, replica) = half2(code[byte & 15], code[byte >> 4]).  Thread t
+// writes replica t & 31 of the byte values whose low nibble is fixed by t >> 5, so its low code is chosen once (a select
+// chain over immediates) and the high code of each store is a compile-time constant: stores only, no reads, one barrier.
+template <int THREADS>
+__device__ __forceinline__ void build_lutp(uint32_t* lut, int tid) {
+    constexpr float tab[16] = M355_NF4_TABLE;
+    constexpr int ROWS = THREADS / 32;          // byte values covered by one pass of the workgroup: 8 or 16
+    static_assert(ROWS == 8 || ROWS == 16, "256 or 512 threads");
+    const int row = tid >> 5;
+    uint32_t* dst = lut + row * 64 + (tid & 31);
+    float lo_a = 0.f, lo_b = 0.f;               // low codes of byte values row (+ 8 in every other pass when ROWS == 8)
 #pragma unroll
-        for (int j = 0; j < 16; j++) c = (tid == j) ? tab[j] : c;
-        codes[tid] = (half_t)c;
+    for (int j = 0; j < 16; j++) {
+        lo_a = (row == j) ? tab[j] : lo_a;
+        lo_b = (row + 8 == j) ? tab[j] : lo_b;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 256 / ROWS; pass++) {
+        const int bv0 = pass * ROWS;             // byte value = bv0 + row
+        const float lo = (ROWS == 16 || (pass & 1) == 0) ? lo_a : lo_b;
+        const half2_t hv = {(half_t)lo, (half_t)tab[bv0 >> 4]};
+        dst[bv0 * 64] = __builtin_bit_cast(uint32_t, hv);
     }
     lds_barrier();
-    for (int i = tid; i < 256 * 32; i += threads) {   // 32 replicas (one per bank) in each 256-byte row
-        const int bv = i >> 5;
-        const half2_t hv = {codes[bv & 15], codes[bv >> 4]};
-        lut[bv * 64 + (i & 31)] = __builtin_bit_cast(uint32_t, hv);
-    }
-    lds_barrier();   // park is free again: everyone is done reading the codes
 }
 
 // INLINE 0: routing lists from the workspace, 1: pairs bucketed here, 2: router too.  KP: K-parts per row-tile pair (the
@@ -490,11 +541,19 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
     half_t* __restrict__ outp, int table_len, RouteIO rio, StageParams sp, const uint8_t* __restrict__ wam8,
     const float* __restrict__ wtab) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef M355_EXP_STAMPS
+    const unsigned long long dbg_entry = __builtin_amdgcn_s_memtime();
+    unsigned long long dbg_pro[4] = {0, 0, 0, 0};
+#define M355_PRO_STAMP(K) dbg_pro[K] = __builtin_amdgcn_s_memtime();
+#else
+#define M355_PRO_STAMP(K)
+#endif
     constexpr int THREADS = PAIRS * KP * 64;
     constexpr int CH = MOE_KPARTS * MOE_CHUNK / KP;                   // blocks per wave and item
     static_assert(CH == 12 || CH == 6, "the item body is written for 12 or 6 blocks per wave");
     static_assert(INLINE == 0 || (KP == MOE_KPARTS && NT == 1), "inline routing is built for the 8-wave, 16-token form");
-    constexpr int RED1 = PAIRS * (KP - 1) * 64 * 8 * NT * 4;          // one reduction buffer
+    static_assert(KP == 4 * NT, "wave q finishes accumulator element q & 3 of token set q >> 2");
+    constexpr int RED1 = PAIRS * KP * 64 * 8 * NT * 4;                // one reduction buffer: every wave's partial sums
     constexpr int RED_ALL = 2 * RED1;                                 // both
     uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
     unsigned char* red = smem + LUTP_BYTES;
@@ -536,6 +595,7 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
         // of those entries are lane reads.
         te_lane = ((int)(threadIdx.x & 63) < table_len) ? tile_expert[threadIdx.x & 63] : 0;
     }
+    M355_PRO_STAMP(0)   /* routing done (or the tile table requested) */
 #define M355_TILE_EXPERT(TT) (INLINE ? __builtin_amdgcn_readfirstlane(rt->tile_e[(TT)]) \
                                      : (((TT) < 64) ? __builtin_amdgcn_readlane(te_lane, (TT)) : tile_expert[(TT)]))
 #define M355_TILE_M0(TT) (INLINE ? __builtin_amdgcn_readfirstlane(rt->tile_m0[(TT)]) : tile_m0[(TT)])
@@ -545,8 +605,10 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
     const int NPG = (NP + PAIRS - 1) / PAIRS;
     // work item = (token tile of one expert, group of PAIRS row-tile pairs); a workgroup takes a contiguous range
     const int total = (INLINE ? __builtin_amdgcn_readfirstlane(rt->nt) : *n_tiles) * NPG;
-    const int it0 = (int)((int64_t)blockIdx.x * total / gridDim.x);
-    const int it1 = (int)((int64_t)(blockIdx.x + 1) * total / gridDim.x);
+    // (one 32-bit division: the first `total % grid` workgroups take one item more)
+    const int per_wg = (int)((uint32_t)total / gridDim.x), extra_wg = total - per_wg * (int)gridDim.x;
+    const int it0 = (int)blockIdx.x * per_wg + min((int)blockIdx.x, extra_wg);
+    const int it1 = it0 + per_wg + ((int)blockIdx.x < extra_wg ? 1 : 0);
     if (it0 >= it1) return;
 
     const int tid = threadIdx.x;
@@ -570,36 +632,50 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
 #pragma unroll
     for (int i = 0; i < CH; i++) voff[i] = (uint32_t)lane * 16u + (uint32_t)(min(bq0 + i, blast) - bq0) * 1024u;
 
-    // aim the ring loads at item IT and request its absmax: lane (n, g) gets rows 4g..4g+3 of both tiles at block
-    // bq0 + n.  The absmax is either fp32 (wam) or, as the checkpoint stores it, one code byte per block (wam8, same
-    // tile order, 4 bytes per lane) with a 256-entry fp32 table per expert (wtab): then the table values of item IT
-    // are gathered with the codes requested one call earlier, and the codes of item IT + 1 are requested now, so
-    // neither load waits for the other.
+    // Absmax of an item: lane (n, g) needs the scales of rows 4g..4g+3 of both tiles at block bq0 + n.  Either fp32 per
+    // block (wam), or, as the checkpoint stores it, one code byte per block (wam8, same tile order, 4 bytes per lane) and
+    // a 256-entry fp32 table per expert (wtab).  The tables of the experts a workgroup is working on sit in LDS (four
+    // slots, slot = token tile & 3: consecutive items lie in the same or in the next tile), so turning codes into scales
+    // costs LDS reads, not a dependent trip to memory: the codes of item IT + 1 are requested while item IT - 1 runs,
+    // looked up at the start of item IT, and the table of a new tile is fetched two items ahead of its first use and
+    // stored just before an item's barrier.
+    float* ltab = reinterpret_cast<float*>(red + RED_ALL + (INLINE ? (int)align_up(sizeof(InlineTables), 16) : 0));
     uint32_t cAn = 0, cBn = 0;
     const int bs_lane = min(bq0 + n, blast);
     const float keep_lane = (bq0 + n < bq1) ? 1.f : 0.f;   // blocks past the K-part count for nothing
-#define M355_CODES_OF(IT)                                                                                     \
+    // An item's place is kept as (token tile, pair group) and stepped from item to item: the kernel divides by the
+    // number of pair groups once.
+#define M355_CODES_OF(POS, CA, CB)                                                                            \
     {                                                                                                         \
-        const int itc_ = min((IT), it1 - 1);                                                                  \
-        const int tt_ = itc_ / NPG, pg_ = itc_ - tt_ * NPG;                                                   \
-        const int e_ = M355_TILE_EXPERT(tt_);                                                                 \
+        const int pg_ = (POS).pg;                                                                             \
+        const int e_ = (POS).e;                                                                               \
         const int pc_ = min(pg_ * PAIRS + pl, NP - 1);                                                        \
         const uint32_t* cm_ = reinterpret_cast<const uint32_t*>(wam8 + (size_t)e_ * am_expert);               \
-        cAn = cm_[((size_t)(pc_ * 2 + 0) * 4 + g) * NB + bs_lane];                                            \
-        cBn = cm_[((size_t)(pc_ * 2 + 1) * 4 + g) * NB + bs_lane];                                            \
+        CA = cm_[((size_t)(pc_ * 2 + 0) * 4 + g) * NB + bs_lane];                                             \
+        CB = cm_[((size_t)(pc_ * 2 + 1) * 4 + g) * NB + bs_lane];                                             \
     }
-#define M355_POINT_AT(IT)                                                                                     \
+    // aim the ring loads at item IT
+#define M355_ADDR_OF(POS)                                                                                     \
     {                                                                                                         \
-        const int tt_ = (IT) / NPG, pg_ = (IT) - tt_ * NPG;                                                   \
-        const int e_ = M355_TILE_EXPERT(tt_);                                                                 \
+        const int pg_ = (POS).pg;                                                                             \
+        const int e_ = (POS).e;                                                                               \
         const int pc_ = min(pg_ * PAIRS + pl, NP - 1);                                                        \
         wbase_next = wq + (size_t)e_ * wq_expert + ((size_t)pc_ * NB + bq0) * 1024;                           \
+    }
+    // the scales of the item at POS into sAn / sBn (byte form: from the codes in cAn / cBn, which then receive those of
+    // the item at NEXT_POS)
+#define M355_SCALES_OF(POS, NEXT_POS, REQUEST_NEXT)                                                           \
+    {                                                                                                         \
+        const int tt_ = (POS).tt;                                                                             \
         if (wam8) {                                                                                           \
-            const float* tab_ = wtab + (size_t)e_ * 256;                                                      \
+            const float* tab_ = ltab + (tt_ & 3) * 256;                                                       \
             sAn = float4_t{tab_[cAn & 0xffu], tab_[(cAn >> 8) & 0xffu], tab_[(cAn >> 16) & 0xffu], tab_[cAn >> 24]} * keep_lane; \
             sBn = float4_t{tab_[cBn & 0xffu], tab_[(cBn >> 8) & 0xffu], tab_[(cBn >> 16) & 0xffu], tab_[cBn >> 24]} * keep_lane; \
-            M355_CODES_OF((IT) + 1)                                                                           \
+            if (REQUEST_NEXT) M355_CODES_OF(NEXT_POS, cAn, cBn)                                               \
         } else {                                                                                              \
+            const int pg_ = (POS).pg;                                                                         \
+            const int e_ = (POS).e;                                                                           \
+            const int pc_ = min(pg_ * PAIRS + pl, NP - 1);                                                    \
             const float4_t* am_ = reinterpret_cast<const float4_t*>(wam + (size_t)e_ * am_expert);            \
             sAn = am_[((size_t)(pc_ * 2 + 0) * 4 + g) * NB + bs_lane] * keep_lane;                            \
             sBn = am_[((size_t)(pc_ * 2 + 1) * 4 + g) * NB + bs_lane] * keep_lane;                            \
@@ -614,15 +690,58 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
     }
 #define M355_NO_LOAD(I)
 
-    if (wam8) M355_CODES_OF(it0)
-    M355_POINT_AT(it0)
+    // Start-up: everything the first item needs from memory is requested at once -- its absmax codes, the absmax tables
+    // of the first two tiles, its weights -- in that order (loads return in order: the small ones first), and the code
+    // table is built in LDS while they are on their way.
+    constexpr int TAB_PER_THREAD = 512 / THREADS;   // two tables, 256 entries each, over the workgroup
+    float tab_first[TAB_PER_THREAD];
+    struct ItemPos { int tt, pg, e; };   // token tile, pair group, the tile's expert (looked up when the tile changes)
+    auto step = [&](ItemPos p_) {
+        p_.pg++;
+        if (p_.pg == NPG) { p_.pg = 0; p_.tt++; p_.e = M355_TILE_EXPERT(p_.tt); }
+        return p_;
+    };
+    ItemPos pos0, pos1, pos2;   // of items it, it + 1, it + 2 (it = the item being worked on); places past the range are clamped to its last item
+    pos0.tt = (int)((uint32_t)it0 / (uint32_t)NPG);
+    pos0.pg = it0 - pos0.tt * NPG;
+    pos0.e = M355_TILE_EXPERT(pos0.tt);
+    pos1 = (it0 + 1 < it1) ? step(pos0) : pos0;
+    pos2 = (it0 + 2 < it1) ? step(pos1) : pos1;
+    const int tt_first = pos0.tt, tt_second = pos1.tt;
+    uint32_t cA1 = 0, cB1 = 0;
+    M355_ADDR_OF(pos0)
+    if (wam8) {
+        M355_CODES_OF(pos0, cAn, cBn)
+        M355_CODES_OF(pos1, cA1, cB1)
+#pragma unroll
+        for (int j = 0; j < TAB_PER_THREAD; j++) {
+            const int i = tid + j * THREADS;
+            const int e_ = i < 256 ? pos0.e : pos1.e;
+            tab_first[j] = wtab[(size_t)e_ * 256 + (i & 255)];
+        }
+    } else {
+        M355_SCALES_OF(pos0, pos1, false)
+    }
 #pragma unroll
     for (int i = 0; i < CH; i++) M355_LOAD(i)
+    M355_PRO_STAMP(1)   /* first loads issued */
+
+    build_lutp<THREADS>(lut, tid);
+    M355_PRO_STAMP(2)   /* code table built */
+    const uint32_t lbase = lutp_lane_base(smem, lane);
+    if (wam8) {
+#pragma unroll
+        for (int j = 0; j < TAB_PER_THREAD; j++) {
+            const int i = tid + j * THREADS;
+            ltab[((i < 256 ? tt_first : tt_second) & 3) * 256 + (i & 255)] = tab_first[j];
+        }
+        lds_barrier();
+        M355_SCALES_OF(pos0, pos1, false)
+        cAn = cA1;   // the second item's codes, requested ahead of the first item's weights
+        cBn = cB1;
+    }
     sA = sAn;
     sB = sBn;
-
-    build_lutp(lut, red, tid, THREADS);   // (while the first weights are on their way)
-    const uint32_t lbase = lutp_lane_base(smem, lane);
 
     // Every wave runs CH blocks per item without branches.  Per block: M355_FETCH (16 table lookups = four A
     // fragments, then the ring load that refills the block's registers), M355_MFMA (four MFMAs per token set against
@@ -630,19 +749,19 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
     // interleaves neighbouring blocks.
 #define M355_FETCH(I, LOAD)                                                                                 \
     {                                                                                                       \
-        fa[0] = lut4p(lbase, W[I][0]);                                                                      \
-        fa[2] = lut4p(lbase, W[I][2]);                                                                      \
-        fa[1] = lut4p(lbase, W[I][1]);                                                                      \
-        fa[3] = lut4p(lbase, W[I][3]);                                                                      \
+        fa[(I) & 1][0] = lut4p(lbase, W[I][0]);                                                             \
+        fa[(I) & 1][2] = lut4p(lbase, W[I][2]);                                                             \
+        fa[(I) & 1][1] = lut4p(lbase, W[I][1]);                                                             \
+        fa[(I) & 1][3] = lut4p(lbase, W[I][3]);                                                             \
         LOAD(I)                                                                                             \
     }
 #define M355_MFMA(I)                                                                                        \
     _Pragma("unroll") for (int s_ = 0; s_ < NT; s_++) {                                                     \
         const float4_t z = {0.f, 0.f, 0.f, 0.f};                                                            \
-        pa[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[0], xb[s_][I][0], z, 0, 0, 0);                   \
-        pb[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[2], xb[s_][I][0], z, 0, 0, 0);                   \
-        pa[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[1], xb[s_][I][1], pa[s_], 0, 0, 0);              \
-        pb[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[3], xb[s_][I][1], pb[s_], 0, 0, 0);              \
+        pa[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[(I) & 1][0], xb[s_][I][0], z, 0, 0, 0);          \
+        pb[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[(I) & 1][2], xb[s_][I][0], z, 0, 0, 0);          \
+        pa[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[(I) & 1][1], xb[s_][I][1], pa[s_], 0, 0, 0);     \
+        pb[s_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[(I) & 1][3], xb[s_][I][1], pb[s_], 0, 0, 0);     \
     }
     // element 0 of each tile goes through instructions the compiler knows (so it places the MFMA-result wait
     // states); the other elements follow as single v_fmac_f32_dpp instructions that depend on element 0's result
@@ -663,26 +782,42 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
 #define M355_MFMA(I)
 #define M355_SCALE(I) accA[0][0] += sA[0]; accB[0][0] += sB[0];
 #endif
-#define M355_BLOCK(I, LOAD) M355_FETCH(I, LOAD) M355_MFMA(I) M355_SCALE(I)
+    // The table lookups of block I + 1 are issued before the MFMAs of block I (two sets of A fragments), so a wave's LDS
+    // latency runs behind its own matrix work instead of in front of it.
+#ifdef M355_EXP_NO_SWPIPE
+#define M355_BLOCK(I, NEXT, LOAD) M355_FETCH(I, LOAD) M355_MFMA(I) M355_SCALE(I)
+#define M355_FIRST_FETCH(LOAD)
+#else
+#define M355_BLOCK(I, NEXT, LOAD) NEXT M355_SCHED_FENCE M355_MFMA(I) M355_SCALE(I)
+#define M355_FIRST_FETCH(LOAD) M355_FETCH(0, LOAD)
+#endif
+#ifdef M355_EXP_STAGGER   /* experiment: the second half of the waves starts every item a little later than its SIMD partners */
+#define M355_STAGGER if (wave >= THREADS / 128) __builtin_amdgcn_s_sleep(M355_EXP_STAGGER);
+#else
+#define M355_STAGGER
+#endif
+#ifdef M355_EXP_SCHED_FENCE
+#define M355_SCHED_FENCE __builtin_amdgcn_sched_barrier(0);
+#else
+#define M355_SCHED_FENCE
+#endif
 
     // One work item.  LOAD is M355_LOAD while another item follows in this workgroup's range (the ring then refills
     // with it) and M355_NO_LOAD for the last one.
 #define M355_ITEM(IT, LOAD, MORE)                                                                           \
     {                                                                                                       \
         const int it = (IT);                                                                                \
-        const int tt = it / NPG, pg = it - tt * NPG;                                                        \
-        const int e = M355_TILE_EXPERT(tt);                                                                 \
-        const int m0 = M355_TILE_M0(tt);                                                                    \
-        const int pos0 = M355_OFFSET(e) + m0;                                                               \
-        const int mt = min(mt_rows, M355_OFFSET(e + 1) - pos0);                                             \
+        const int tt = pos0.tt, pg = pos0.pg, e = pos0.e;                                                   \
         const int p = pg * PAIRS + pl;                                                                      \
         const bool live = p < NP;                                                                           \
         if (tt != staged_tile) {                                                                            \
+            row0 = M355_OFFSET(e) + M355_TILE_M0(tt);                                                       \
+            mt = min(mt_rows, M355_OFFSET(e + 1) - row0);                                                   \
             /* this lane's B fragments of the whole K-part: token rows n, n + 16, .. (clamped), columns */  \
             /* 64b + 16g .. + 15 of each block, from global memory into registers, where they stay until */ \
             /* the token tile changes */                                                                    \
             _Pragma("unroll") for (int s_ = 0; s_ < NT; s_++) {                                             \
-                const int pos = pos0 + min(n + 16 * s_, mt - 1);                                            \
+                const int pos = row0 + min(n + 16 * s_, mt - 1);                                            \
                 const int64_t src_row = (MODE == 0) ? (int64_t)(M355_PAIR_AT(pos) / k_top) : (int64_t)pos;  \
                 const u32x4_t* src = reinterpret_cast<const u32x4_t*>(xin + src_row * K) + 2 * g;           \
                 _Pragma("unroll") for (int i = 0; i < CH; i++) {                                            \
@@ -693,63 +828,112 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
             }                                                                                               \
             staged_tile = tt;                                                                               \
         }                                                                                                   \
-        if (MORE) M355_POINT_AT(it + 1)                                                                     \
+        /* the table of a tile that starts two items from here: requested now, stored before this item's barrier */ \
+        float tab_new = 0.f;                                                                                \
+        int tab_slot = -1;                                                                                  \
+        if (MORE) {                                                                                         \
+            M355_ADDR_OF(pos1)                                                                              \
+            M355_SCALES_OF(pos1, pos2, true)                                                                \
+            if (wam8 && it + 2 < it1) {                                                                     \
+                const int t2_ = pos2.tt;                                                                    \
+                if (t2_ != pos1.tt) {                                                                       \
+                    tab_slot = t2_ & 3;                                                                     \
+                    if (THREADS == 256 || tid < 256) tab_new = wtab[(size_t)pos2.e * 256 + (tid & 255)];    \
+                }                                                                                           \
+            }                                                                                               \
+        }                                                                                                   \
         float4_t accA[NT], accB[NT];                                                                        \
         _Pragma("unroll") for (int s_ = 0; s_ < NT; s_++) {                                                 \
             accA[s_] = float4_t{0.f, 0.f, 0.f, 0.f};                                                        \
             accB[s_] = float4_t{0.f, 0.f, 0.f, 0.f};                                                        \
         }                                                                                                   \
-        half8_t fa[4];                                                                                      \
+        half8_t fa[2][4];                                                                                   \
         float4_t pa[NT], pb[NT];                                                                            \
-        M355_BLOCK(0, LOAD) M355_BLOCK(1, LOAD) M355_BLOCK(2, LOAD) M355_BLOCK(3, LOAD)                     \
-        M355_BLOCK(4, LOAD) M355_BLOCK(5, LOAD)                                                             \
+        M355_STAMP()                                                                                        \
+        M355_STAGGER                                                                                        \
+        M355_FIRST_FETCH(LOAD)                                                                              \
+        M355_BLOCK(0, M355_FETCH(1, LOAD), LOAD) M355_BLOCK(1, M355_FETCH(2, LOAD), LOAD)                   \
+        M355_BLOCK(2, M355_FETCH(3, LOAD), LOAD) M355_BLOCK(3, M355_FETCH(4, LOAD), LOAD)                   \
+        M355_BLOCK(4, M355_FETCH(5, LOAD), LOAD)                                                            \
         if constexpr (CH > 6) {                                                                             \
-            M355_BLOCK(6, LOAD) M355_BLOCK(7, LOAD) M355_BLOCK(8, LOAD) M355_BLOCK(9, LOAD)                 \
-            M355_BLOCK(10, LOAD) M355_BLOCK(11, LOAD)                                                       \
+            M355_BLOCK(5, M355_FETCH(6, LOAD), LOAD) M355_BLOCK(6, M355_FETCH(7, LOAD), LOAD)               \
+            M355_BLOCK(7, M355_FETCH(8, LOAD), LOAD) M355_BLOCK(8, M355_FETCH(9, LOAD), LOAD)               \
+            M355_BLOCK(9, M355_FETCH(10, LOAD), LOAD) M355_BLOCK(10, M355_FETCH(11, LOAD), LOAD)            \
+            M355_BLOCK(11, , LOAD)                                                                          \
+        } else {                                                                                            \
+            M355_BLOCK(5, , LOAD)                                                                           \
         }                                                                                                   \
+        M355_STAMP()                                                                                        \
         sA = sAn;                                                                                           \
         sB = sBn;                                                                                           \
-        /* sum the K-parts through LDS (two buffers in turn, so one barrier per item is enough) */          \
-        float4_t* rbuf = reinterpret_cast<float4_t*>(red + (round & 1) * RED1);                             \
+        /* Sum of the K-parts and epilogue, shared out: every wave leaves its partial sums in LDS (element-major, so */ \
+        /* that both the stores and the reads below touch every bank once), and after the item's one barrier (two  */ \
+        /* buffers in turn) wave q finishes accumulator element q & 3 of token set q >> 2 for all lanes: the four  */ \
+        /* (or eight) partial values are added in K-part order, then bias, activation and one 2-byte store.        */ \
+        float* rbuf = reinterpret_cast<float*>(red + (round & 1) * RED1) + (size_t)pl * (KP * NT * 8 * 64);   \
         round++;                                                                                            \
-        if (q > 0) {                                                                                        \
-            float4_t* dst = rbuf + ((size_t)(pl * (KP - 1) + (q - 1)) * 64 + lane) * 2 * NT;                \
-            _Pragma("unroll") for (int s_ = 0; s_ < NT; s_++) {                                             \
-                dst[2 * s_] = accA[s_];                                                                     \
-                dst[2 * s_ + 1] = accB[s_];                                                                 \
+        _Pragma("unroll") for (int s_ = 0; s_ < NT; s_++)                                                   \
+            _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                 \
+                rbuf[((q * NT + s_) * 8 + r) * 64 + lane] = accA[s_][r];                                    \
+                rbuf[((q * NT + s_) * 8 + 4 + r) * 64 + lane] = accB[s_][r];                                \
             }                                                                                               \
-        }                                                                                                   \
+        if (tab_slot >= 0 && (THREADS == 256 || tid < 256)) ltab[tab_slot * 256 + (tid & 255)] = tab_new;   \
         lds_barrier();                                                                                      \
-        if (q == 0 && live) {                                                                               \
-            _Pragma("unroll") for (int qq = 0; qq < KP - 1; qq++) {                                         \
-                const float4_t* src = rbuf + ((size_t)(pl * (KP - 1) + qq) * 64 + lane) * 2 * NT;           \
-                _Pragma("unroll") for (int s_ = 0; s_ < NT; s_++) {                                         \
-                    accA[s_] += src[2 * s_];                                                                \
-                    accB[s_] += src[2 * s_ + 1];                                                            \
-                }                                                                                           \
+        M355_STAMP()                                                                                        \
+        {                                                                                                   \
+            const int s_ = q >> 2, r = q & 3;                                                               \
+            float sumA = 0.f, sumB = 0.f;                                                                   \
+            _Pragma("unroll") for (int qq = 0; qq < KP; qq++) {                                             \
+                sumA += rbuf[((qq * NT + s_) * 8 + r) * 64 + lane];                                         \
+                sumB += rbuf[((qq * NT + s_) * 8 + 4 + r) * 64 + lane];                                     \
             }                                                                                               \
-            _Pragma("unroll") for (int s_ = 0; s_ < NT; s_++)                                               \
-                if (n + 16 * s_ < mt) gemm_epilogue<MODE>(accA[s_], accB[s_], outp, pos0 + n + 16 * s_, R, NP, p, g, e, sp); \
+            if (live && n + 16 * s_ < mt) gemm_epilogue1<MODE>(sumA, sumB, outp, row0 + n + 16 * s_, R, NP, p, 4 * g + r, e, sp); \
         }                                                                                                   \
+        pos0 = pos1;                                                                                        \
+        pos1 = pos2;                                                                                        \
+        if (it + 3 < it1) pos2 = step(pos2);                                                                \
+        M355_STAMP()                                                                                        \
     }
 
-    int staged_tile = -1;
+#ifdef M355_EXP_STAMPS
+    int dbg_n = 0;
+    if ((wave & 3) == 0) {   // kernel entry (cycles, 100 MHz wall clock), start of the item loop
+        const unsigned long long t0_ = __builtin_amdgcn_s_memtime(), r0_ = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long* d_ = m355_dbg + ((size_t)(blockIdx.x & 511) * 2 + (wave >> 2)) * 128;
+            d_[0] = dbg_entry; d_[1] = r0_; d_[2] = (unsigned long long)(it1 - it0); d_[3] = 0; d_[4] = t0_;
+            d_[124] = dbg_pro[0]; d_[125] = dbg_pro[1]; d_[126] = dbg_pro[2];
+        }
+        dbg_n = 1;
+    }
+#endif
+    int staged_tile = -1, row0 = 0, mt = 0;   // the token tile whose activations are in registers: its first row and size
     int round = 0;
     half8_t xb[NT][CH][2];
     for (int itx = it0; itx < it1 - 1; itx++) M355_ITEM(itx, M355_LOAD, true)
     M355_ITEM(it1 - 1, M355_NO_LOAD, false)
+#ifdef M355_EXP_STAMPS
+    if ((wave & 3) == 0) {
+        const unsigned long long r1_ = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) m355_dbg[((size_t)(blockIdx.x & 511) * 2 + (wave >> 2)) * 128 + 3] = r1_;
+    }
+#endif
 #undef M355_ITEM
 #undef M355_TILE_EXPERT
 #undef M355_TILE_M0
 #undef M355_OFFSET
 #undef M355_PAIR_AT
 #undef M355_BLOCK
+#undef M355_FIRST_FETCH
+#undef M355_STAGGER
+#undef M355_SCHED_FENCE
 #undef M355_SCALE
 #undef M355_MFMA
 #undef M355_FETCH
 #undef M355_NO_LOAD
 #undef M355_LOAD
-#undef M355_POINT_AT
+#undef M355_SCALES_OF
+#undef M355_ADDR_OF
 #undef M355_CODES_OF
 }
 
@@ -819,8 +1003,10 @@ int moe_device_init(int dev) {
 // mean (token, k) pairs per local expert from which the tile kernel takes over
 constexpr int TILE_MIN_MEAN_PAIRS = 68;   // measured crossover against the 32-token streaming form on gpt-oss-20b shapes (32 experts: about 540 tokens)
 
+constexpr int ABSMAX_TABLE_SLOTS_BYTES = 4 * 256 * 4;   // four experts' absmax tables (byte form)
 static int stream_lds_bytes(int pairs, int inline_route, int kparts = MOE_KPARTS, int token_sets = 1) {   // (activations live in registers)
-    return LUTP_BYTES + 2 * pairs * (kparts - 1) * 64 * 8 * token_sets * 4 + (inline_route ? (int)align_up(sizeof(InlineTables), 16) : 0);
+    return LUTP_BYTES + 2 * pairs * kparts * 64 * 8 * token_sets * 4 + (inline_route ? (int)align_up(sizeof(InlineTables), 16) : 0) +
+           ABSMAX_TABLE_SLOTS_BYTES;
 }
 
 // A gate_up launch can bucket the pairs itself when a pair per thread and two experts per lane cover them.
@@ -851,7 +1037,12 @@ static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, c
                 return 0;
             }
         }
-        if (2 * items2 >= cus) {   // 8-wave workgroups unless even those would leave most CUs idle
+#ifdef M355_EXP_PAIRS1_SMALL   /* experiment: single-pair items, two 4-wave workgroups per CU, for a handful of tokens */
+        const bool small_batch = ws.max_pairs / k_top <= 8;
+#else
+        const bool small_batch = false;
+#endif
+        if (2 * items2 >= cus && !small_batch) {   // 8-wave workgroups unless even those would leave most CUs idle
             const int lds = stream_lds_bytes(2, INLINE);
             const int grid = items2 < cus ? items2 : cus;
             moe_gemm_stream_kernel<MODE, 2, INLINE><<<dim3(grid), dim3(512), lds, st>>>(
@@ -883,6 +1074,12 @@ static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, c
 }  // namespace m355
 
 using namespace m355;
+
+#ifdef M355_EXP_STAMPS
+extern "C" __attribute__((visibility("default"))) int m355_dbg_read(void* host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(m355_dbg), bytes < sizeof(m355_dbg) ? bytes : sizeof(m355_dbg));
+}
+#endif
 
 extern "C" size_t m355_moe_workspace_bytes(int T, int k, int H, int FF, int E_local) {
     if (T < 0 || k <= 0 || H <= 0 || FF <= 0 || E_local <= 0) return 0;
