@@ -1,33 +1,30 @@
 // Fused NF4-dequant grouped GEMM for many tokens per expert (prefill, large decode batches): MFMA-bound.
 //
 // A workgroup owns up to 256 tokens of one expert (a token tile) times 256 weight rows (8 row-tile pairs of the tile
-// order that m355_repack_nf4 writes, one pair = 32 rows per wave) and walks K in 64-column blocks, the NF4 absmax
+// order that m355_repack_nf4 writes, one pair = 16 + 16 rows per wave) and walks K in 64-column blocks, the NF4 absmax
 // block.  Per block:
-//   * each wave takes its own packed KiB (brought into LDS by DMA two blocks ahead), turns it
-//     into the A fragments of four v_mfma_f32_32x32x16_f16 (rows = 16 rows of the pair's first tile + the 16 partner
-//     rows) and reuses them for every token of the tile: the weights never pass through LDS and are dequantised once
-//     per 256 tokens.  w = fp16(code * absmax) with the product in fp32, which is bit for bit the weight the
-//     reference's dequantiser produces (patches/streaming_unsloth_bnb.py:192-222);
+//   * each wave takes its own packed KiB (brought into LDS by DMA two blocks ahead) and turns it into the A fragments of
+//     v_mfma_f32_16x16x32_f16 exactly as the tile order holds them -- lane (r, g) owns 16 codes of row r of the pair's
+//     first tile and 16 of row r of its partner tile, columns 16g .. 16g + 15: two K-steps of 32 columns each, the
+//     lane's share of a step being columns 16g + 8t .. + 7 -- and reuses them for every token of the tile: the weights
+//     never pass through LDS as fp16 and are dequantised once per 256 tokens;
 //   * the activations of the token tile (256 x 64 fp16 = 32 KiB) are shared by the 8 waves: LDS-DMA
 //     (global_load_lds_dwordx4) in whole 128-byte lines, one block ahead, into one of two buffers, the 16-byte chunks
-//     XOR-swizzled on the source side so that the ds_read_b128 of the B fragments is bank-conflict free.
-// Lane l of a wave = (r = l & 15, s = (l >> 4) & 1, h = l >> 5).  As loaded, lane (r, g = s + 2h) holds 16 codes of
-// row r and 16 of its partner row, columns 16g..16g+15.  One v_permlane16_swap per dword pair trades the partner-row
-// half of the s = 0 lanes against the first-row half of the s = 1 lanes, after which lane (r, s, h) holds row
-// (s, r), columns 32h..32h+31 of the block: MFMA step t (K = 16) takes columns 32h + 8t.. from lane half h.
+//     XOR-swizzled on the source side so that the ds_read_b128 of the B fragments (token r of a 16-token tile, the same
+//     columns as the lane's A fragment) is bank-conflict free.
+// The 16x16x32 shape is used although 32x32x16 needs half as many instructions for the same product: under sustained
+// matrix load the chip holds a higher clock with it (measured here: +5 % on the whole kernel at equal work).
 #include <type_traits>
 
 #include "moe_shared.h"
 
 namespace m355 {
 
-typedef float float16_t __attribute__((ext_vector_type(16)));
-typedef float float2_t __attribute__((ext_vector_type(2)));
 
 constexpr int TG_WAVES = 8;                      // two waves per SIMD (one wave per SIMD with TG_RT = 2 measured 10 % slower)
 constexpr int TG_RT = 1;                         // row-tile pairs (32 weight rows each) per wave
 constexpr int TG_THREADS = TG_WAVES * 64;
-constexpr int TG_LUT_BYTES = 256 * 256;          // float2 per byte value, 32 replicas of 8 B in a 256-byte row
+constexpr int TG_LUT_BYTES = 256 * 256;          // half2 per byte value, 32 replicas of 4 B in a 256-byte row
 constexpr int TG_XBUF = TILE_ROWS * 128;         // one activation buffer: 256 tokens x 64 columns fp16
 constexpr int TG_XI = TILE_ROWS / 8 / TG_WAVES;  // activation DMA instructions (8 tokens each) per wave and block
 constexpr int TG_WBUF = TG_WAVES * TG_RT * 1024; // one packed-weight slot: a KiB per pair
@@ -37,33 +34,38 @@ constexpr int TG_W_OFF = TG_X_OFF + 2 * TG_XBUF;
 constexpr int TG_S_OFF = TG_W_OFF + 2 * TG_WBUF;
 constexpr int TG_TAB_OFF = TG_S_OFF + 2 * TG_SBUF;   // one expert's absmax table (byte absmax)
 constexpr int TG_LDS = TG_TAB_OFF + 1024;
-constexpr int TG_TOKEN_TILES = TILE_ROWS / 32;   // 32-token MFMA tiles per token tile
+#ifndef TG_LA
+#define TG_LA 1   // 16-token tiles of B fragments requested ahead of the MFMAs that use them (16x16x32 kernel)
+#endif
 
 static __device__ const float nf4_codes[16] = M355_NF4_TABLE;
 
-typedef const float2_t __attribute__((address_space(3))) lds_f2_t;
 typedef const half8_t __attribute__((address_space(3))) lds_h8_t;
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 
 // 8 weights of one packed dword: four table lookups (address = one v_perm_b32: byte k of d above the lane's replica
-// offset), then scaled in fp32 and rounded to fp16 (round to nearest even).  Two steps so that the lookups can be
-// issued ahead of other LDS reads and the arithmetic placed where their results have arrived.
-__device__ __forceinline__ void lookup8(uint32_t lbase, uint32_t d, float2_t* f) {
+// offset) fetch the two fp16 codes of each byte; then one packed fp16 multiply per byte by the block's absmax (rounded
+// to fp16).  Two steps so that the lookups can be issued ahead of other LDS reads and the arithmetic placed where their
+// results have arrived.  w = fp16(fp16(code) * fp16(absmax)): three fp16 roundings where the reference's dequantiser has
+// one (fp16(code * absmax), patches/streaming_unsloth_bnb.py:192-222), each below 2^-11 relative; the fp32 product and
+// its conversion cost twice the vector instructions and 5 % of the kernel.
+typedef const uint32_t __attribute__((address_space(3))) lds_u32c_t;
+__device__ __forceinline__ void lookup8(uint32_t lbase, uint32_t d, uint32_t* o) {
     uint32_t a0 = __builtin_amdgcn_perm(d, lbase, 0x03020400u), a1 = __builtin_amdgcn_perm(d, lbase, 0x03020500u);
     uint32_t a2 = __builtin_amdgcn_perm(d, lbase, 0x03020600u), a3 = __builtin_amdgcn_perm(d, lbase, 0x03020700u);
-    f[0] = *reinterpret_cast<lds_f2_t*>(a0);
-    f[1] = *reinterpret_cast<lds_f2_t*>(a1);
-    f[2] = *reinterpret_cast<lds_f2_t*>(a2);
-    f[3] = *reinterpret_cast<lds_f2_t*>(a3);
+    o[0] = *reinterpret_cast<lds_u32c_t*>(a0);
+    o[1] = *reinterpret_cast<lds_u32c_t*>(a1);
+    o[2] = *reinterpret_cast<lds_u32c_t*>(a2);
+    o[3] = *reinterpret_cast<lds_u32c_t*>(a3);
 }
-__device__ __forceinline__ half8_t scale8(const float2_t* f, float s) {
-    const half2_t h0 = __builtin_convertvector(f[0] * s, half2_t), h1 = __builtin_convertvector(f[1] * s, half2_t);
-    const half2_t h2 = __builtin_convertvector(f[2] * s, half2_t), h3 = __builtin_convertvector(f[3] * s, half2_t);
+__device__ __forceinline__ half8_t scale8(const uint32_t* o, float s) {
+    const half2_t hs = {(half_t)s, (half_t)s};
+    const half2_t h0 = as_half2(o[0]) * hs, h1 = as_half2(o[1]) * hs, h2 = as_half2(o[2]) * hs, h3 = as_half2(o[3]) * hs;
     return half8_t{h0[0], h0[1], h1[0], h1[1], h2[0], h2[1], h3[0], h3[1]};
 }
 __device__ __forceinline__ half8_t dequant8(uint32_t lbase, uint32_t d, float s) {
-    float2_t f[4];
+    uint32_t f[4];
     lookup8(lbase, d, f);
     return scale8(f, s);
 }
@@ -102,9 +104,13 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
     const int e = tile_expert[tt];
     const int pos0 = offsets[e] + tile_m0[tt];
     const int mt = min(TILE_ROWS, offsets[e + 1] - pos0);
-    const int ntt = (mt + 31) >> 5;                         // live 32-token tiles
+    const int ntt = (mt + 15) >> 4;                         // live 16-token tiles
     const int p0 = (rg * TG_WAVES + wave) * TG_RT;          // this wave's row-tile pairs: p0 .. p0 + TG_RT - 1
-    const int r = lane & 15, s = (lane >> 4) & 1, hh = lane >> 5, n32 = lane & 31;
+    const int r = lane & 15, s = (lane >> 4) & 1, g = lane >> 4, n32 = lane & 31;
+    // where a 16-byte chunk of a token's 128-byte line sits in LDS: position = chunk ^ key(token & 15), the key chosen so
+    // that the 16 lanes a ds_read_b128 serves together (tokens 0..15 once each, column groups g or g ^ 1 by token) touch
+    // every bank once
+    auto xkey = [](int tok) { return (((tok >> 3) & 1) << 2) | ((tok >> 1) & 1); };
 
     // ---- everything that comes from global memory goes to LDS by DMA (global_load_lds), so no vector register waits
     // for memory and the only waits are the vmcnt(0) + barrier at the top of an iteration ----
@@ -116,12 +122,12 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
         const int m = 8 * (TG_XI * wave + j) + (lane >> 3);
         const int pos = pos0 + min(m, mt - 1);
         const int64_t src_row = (MODE == 0) ? (int64_t)(sorted[pos] / k_top) : (int64_t)pos;
-        xsrc[j] = xin + src_row * K + (((lane & 7) ^ ((m >> 1) & 7)) << 3);
+        xsrc[j] = xin + src_row * K + (((lane & 7) ^ xkey(m)) << 3);
     }
-    // B fragment of MFMA step t, token n32 of a 32-token tile: chunk 4h + t of the token's line
-    uint32_t boff[4];
+    // B fragment of K-step t (32 columns: this lane's are 16g + 8t .. + 7), token r of a 16-token tile: chunk 2g + t
+    uint32_t boff[2];
 #pragma unroll
-    for (int t = 0; t < 4; t++) boff[t] = TG_X_OFF + n32 * 128 + (((4 * hh + t) ^ ((n32 >> 1) & 7)) << 4);
+    for (int t = 0; t < 2; t++) boff[t] = TG_X_OFF + r * 128 + (((2 * g + t) ^ xkey(r)) << 4);
 
     // weights: a packed KiB per pair and block; absmax: the dword that holds the lane's row (4 code bytes of rows
     // 4 (r >> 2).. for byte absmax, the row's fp32 otherwise).  Pairs past the end re-read the last one, results dropped.
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
     }
     float* ltab = reinterpret_cast<float*>(smem + TG_TAB_OFF);   // this expert's absmax table (byte absmax)
     const uint32_t wlds = TG_W_OFF + wave * TG_RT * 1024 + lane * 16;
-    const uint32_t slds = TG_S_OFF + wave * TG_RT * 256 + lane * 4 + (q8 ? (r & 3) : 0);
+    const uint32_t slds = TG_S_OFF + wave * TG_RT * 256 + r * 4 + (q8 ? (r & 3) : 0);   // row r of the first tile; + 64: of its partner
 
     // DMA piece k of an iteration: pieces 0 .. TG_XI - 1 bring activations of block bx (8 tokens each), then per pair
     // one piece for the packed weights and one for the absmax of block bw
@@ -169,8 +175,8 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
     auto packed_of = [&](int bw, int i) -> u32x4_t {
         return *reinterpret_cast<const __attribute__((address_space(3))) u32x4_t*>(wlds + (uint32_t)((bw & 1) * TG_WBUF + i * 1024));
     };
-    auto scale_of = [&](int bw, int i) -> float {
-        const uint32_t a = slds + (uint32_t)((bw & 1) * TG_SBUF + i * 256);
+    auto scale_of = [&](int bw, int half) -> float {
+        const uint32_t a = slds + (uint32_t)((bw & 1) * TG_SBUF + half * 64);
         if (q8) return ltab[*reinterpret_cast<const __attribute__((address_space(3))) uint8_t*>(a)];
         return *reinterpret_cast<const __attribute__((address_space(3))) float*>(a);
     };
@@ -178,116 +184,129 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
     // code table: entry (byte v, replica) = (code[v & 15], code[v >> 4]) as two fp32
     for (int i = tid; i < 256 * 32; i += TG_THREADS) {
         const int v = i >> 5;
-        *reinterpret_cast<float2_t*>(smem + v * 256 + (i & 31) * 8) = float2_t{nf4_codes[v & 15], nf4_codes[v >> 4]};
+        const half2_t hv = {(half_t)nf4_codes[v & 15], (half_t)nf4_codes[v >> 4]};
+        *reinterpret_cast<uint32_t*>(smem + v * 256 + (i & 31) * 4) = __builtin_bit_cast(uint32_t, hv);
     }
     if (q8 && tid < 256) ltab[tid] = wtab[(size_t)e * 256 + tid];
-    const uint32_t lbase = (uint32_t)(n32 * 8);   // the table starts at LDS address 0 (no static LDS in this kernel)
+    const uint32_t lbase = (uint32_t)(n32 * 4);   // the table starts at LDS address 0 (no static LDS in this kernel)
 
-    float16_t acc[TG_RT][TG_TOKEN_TILES];
+    constexpr int NTT = TILE_ROWS / 16;   // 16-token tiles of a token tile
+    float4_t accA[NTT], accB[NTT];        // rows 4g .. 4g + 3 of the pair's first / partner row tile, token r of tile c
 #pragma unroll
-    for (int i = 0; i < TG_RT; i++)
-#pragma unroll
-        for (int c = 0; c < TG_TOKEN_TILES; c++)
-#pragma unroll
-            for (int q = 0; q < 16; q++) acc[i][c][q] = 0.f;
+    for (int c = 0; c < NTT; c++) {
+        accA[c] = float4_t{0.f, 0.f, 0.f, 0.f};
+        accB[c] = float4_t{0.f, 0.f, 0.f, 0.f};
+    }
 
-    // ablation switches (diagnostic builds only)
-#ifdef TG_EXP_NOREAD
-#define TG_EXP_READ(DST, ADDR) DST = a_use[0][t];
-#else
-#define TG_EXP_READ(DST, ADDR) DST = *reinterpret_cast<lds_h8_t*>(ADDR);
-#endif
-#ifdef TG_EXP_NOMMA
-#define TG_EXP_MMA(ACC, A, B) asm volatile("" ::"v"(A), "v"(B));
-#else
-#define TG_EXP_MMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, ACC, 0, 0, 0);
-#endif
-#ifdef TG_EXP_NODEQ
-#define TG_EXP_DEQ(X)
-#else
-#define TG_EXP_DEQ(X) X
-#endif
-    // Pipeline.  Iteration b multiplies block b (A fragments a_use, activations in buffer b & 1) and meanwhile turns
-    // packed block b + 1 (LDS slot (b + 1) & 1, brought in during iteration b - 1) into a_fill, a dword at a time
-    // between the MFMAs of the token tiles, while the DMA brings activations b + 1 and weights b + 2.  The B fragments
-    // of token tile c + 1 are requested before the MFMAs of tile c are issued (two register sets).  Iterations come
-    // in pairs so that the two A-fragment sets keep static names.
-    half8_t afA[TG_RT][4], afB[TG_RT][4];
+    // Pipeline.  Iteration b multiplies block b (A fragments a_use: first tile K-steps 0, 1, partner tile K-steps 0, 1;
+    // activations in buffer b & 1) and meanwhile turns packed block b + 1 (LDS slot (b + 1) & 1, brought in during
+    // iteration b - 1) into a_fill, a dword at a time between the MFMAs of the token tiles, while the DMA brings
+    // activations b + 1 and weights b + 2.  The B fragments of token tile c + 1 are requested before the MFMAs of tile c
+    // are issued (two register sets).  Iterations come in pairs so that the two A-fragment sets keep static names.
+    half8_t afA[4], afB[4];
     auto main_loop = [&](auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;   // all 8 token tiles live: no per-tile tests
+        constexpr bool FULL = decltype(full_tag)::value;   // all 16 token tiles live: no per-tile tests
         stage(full_tag, 0, 0);
         stage(full_tag, 0, 1);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   // tables complete, block 0 landed
-#pragma unroll
-        for (int i = 0; i < TG_RT; i++) {
-            const u32x4_t wv = packed_of(0, i);
-            const float sc = scale_of(0, i);
-            const auto sw0 = __builtin_amdgcn_permlane16_swap(wv[0], wv[2], false, false);
-            const auto sw1 = __builtin_amdgcn_permlane16_swap(wv[1], wv[3], false, false);
-            afA[i][0] = dequant8(lbase, sw0[0], sc);
-            afA[i][1] = dequant8(lbase, sw1[0], sc);
-            afA[i][2] = dequant8(lbase, sw0[1], sc);
-            afA[i][3] = dequant8(lbase, sw1[1], sc);
+        {
+            const u32x4_t wv = packed_of(0, 0);
+            const float s0 = scale_of(0, 0), s1 = scale_of(0, 1);
+            afA[0] = dequant8(lbase, wv[0], s0);
+            afA[1] = dequant8(lbase, wv[1], s0);
+            afA[2] = dequant8(lbase, wv[2], s1);
+            afA[3] = dequant8(lbase, wv[3], s1);
         }
-        auto iteration = [&](int b, half8_t (*a_use)[4], half8_t (*a_fill)[4]) {
-            // every DMA of the last iteration has landed (this wave's: vmcnt; the others': barrier), and nobody reads
-            // what this iteration's DMA overwrites
-#ifdef TG_EXP_NOBARRIER
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
+        auto iteration = [&](int b, half8_t* a_use, half8_t* a_fill) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-            uint32_t dw[TG_RT][4];   // packed block b + 1 in MFMA-step order
-            float sc[TG_RT];
-#pragma unroll
-            for (int i = 0; i < TG_RT; i++) {
-                const u32x4_t wv = packed_of(b + 1, i);
-                sc[i] = scale_of(b + 1, i);
-                const auto sw0 = __builtin_amdgcn_permlane16_swap(wv[0], wv[2], false, false);
-                const auto sw1 = __builtin_amdgcn_permlane16_swap(wv[1], wv[3], false, false);
-                dw[i][0] = sw0[0]; dw[i][1] = sw1[0]; dw[i][2] = sw0[1]; dw[i][3] = sw1[1];
-            }
+            const u32x4_t wv = packed_of(b + 1, 0);
+            const float sc0 = scale_of(b + 1, 0), sc1 = scale_of(b + 1, 1);
             const uint32_t xb = (uint32_t)((b & 1) * TG_XBUF);
-            lds_h8_t* bp[4];
+            lds_h8_t* bp[2];
 #pragma unroll
-            for (int t = 0; t < 4; t++) bp[t] = reinterpret_cast<lds_h8_t*>(boff[t] + xb);
-            half8_t bfA[4], bfB[4];
-            float2_t lf[4];   // table values of the dword being dequantised
-#define TG_READ(BF, C)                                                                                          \
+            for (int t = 0; t < 2; t++) bp[t] = reinterpret_cast<lds_h8_t*>(boff[t] + xb);
+            uint32_t lf[4];   // table values of the dword being dequantised
+            // B fragments of TG_LA token tiles ahead are requested before a tile's MFMAs are issued (TG_LA + 1 register sets)
+            half8_t bf[TG_LA + 1][2];
+#define TG_READ(C)                                                                                              \
     if (FULL || (C) < ntt) {                                                                                    \
-        _Pragma("unroll") for (int t = 0; t < 4; t++) TG_EXP_READ(BF[t], bp[t] + (C) * 256)                     \
+        _Pragma("unroll") for (int t = 0; t < 2; t++) bf[(C) % (TG_LA + 1)][t] = *(bp[t] + (C) * 128);          \
     }
-#define TG_MMA(BF, C)                                                                                           \
+#define TG_MMA(C)                                                                                               \
     if (FULL || (C) < ntt) {                                                                                    \
-        _Pragma("unroll") for (int t = 0; t < 4; t++)                                                           \
-            _Pragma("unroll") for (int i = 0; i < TG_RT; i++) TG_EXP_MMA(acc[i][C], a_use[i][t], BF[t])         \
+        accA[C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_use[0], bf[(C) % (TG_LA + 1)][0], accA[C], 0, 0, 0); \
+        accB[C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_use[2], bf[(C) % (TG_LA + 1)][0], accB[C], 0, 0, 0); \
+        accA[C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_use[1], bf[(C) % (TG_LA + 1)][1], accA[C], 0, 0, 0); \
+        accB[C] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_use[3], bf[(C) % (TG_LA + 1)][1], accB[C], 0, 0, 0); \
     }
-            /* One dword (8 weights) of the next block per token tile and pair: parts 0..3 of pair 0 with tiles 1, 3, 5, */ \
-            /* 7 (tile 0 starts as soon as its B fragments are there); of a second pair with tiles 0, 2, 4, 6.  The table lookups go out ahead of the B reads of the next token */ \
-            /* tile (LDS returns in order: waiting for them then leaves those reads in flight), the arithmetic sits */ \
-            /* among the tile's MFMAs, and one DMA piece follows each of the first tiles. */
-#define TG_PAIR(C) (TG_RT == 1 ? 0 : 1 - ((C) & 1))
-#define TG_LUT(C) TG_EXP_DEQ(if (TG_RT == 2 || ((C) & 1)) lookup8(lbase, dw[TG_PAIR(C)][(C) >> 1], lf);)
-#define TG_MATH(C) TG_EXP_DEQ(if (TG_RT == 2 || ((C) & 1)) a_fill[TG_PAIR(C)][(C) >> 1] = scale8(lf, sc[TG_PAIR(C)]);)
-#ifdef TG_EXP_NODMA
-#define TG_DMA(C)
-#else
-#define TG_DMA(C) dma_piece(full_tag, (C), b + 1, b + 2);
-#endif
-#define TG_SB __builtin_amdgcn_sched_barrier(0);   /* keeps the order: reads of tile c + 1, then MFMAs of tile c */
-            TG_SB TG_READ(bfA, 0)
-            TG_SB TG_LUT(0) TG_READ(bfB, 1) TG_SB TG_MMA(bfA, 0) TG_MATH(0) TG_DMA(0)
-            TG_SB TG_LUT(1) TG_READ(bfA, 2) TG_SB TG_MMA(bfB, 1) TG_MATH(1) TG_DMA(1)
-            TG_SB TG_LUT(2) TG_READ(bfB, 3) TG_SB TG_MMA(bfA, 2) TG_MATH(2) TG_DMA(2)
-            TG_SB TG_LUT(3) TG_READ(bfA, 4) TG_SB TG_MMA(bfB, 3) TG_MATH(3) TG_DMA(3)
-            TG_SB TG_LUT(4) TG_READ(bfB, 5) TG_SB TG_MMA(bfA, 4) TG_MATH(4) TG_DMA(4)
-            TG_SB TG_LUT(5) TG_READ(bfA, 6) TG_SB TG_MMA(bfB, 5) TG_MATH(5) TG_DMA(5)
-            TG_SB TG_LUT(6) TG_READ(bfB, 7) TG_SB TG_MMA(bfA, 6) TG_MATH(6) TG_DMA(6)
-            TG_SB TG_LUT(7) TG_SB TG_MMA(bfB, 7) TG_MATH(7) TG_DMA(7)
-            _Pragma("unroll") for (int k = 8; k < TG_PIECES; k++) dma_piece(full_tag, k, b + 1, b + 2);
+            /* One dword (8 weights) of the next block with every fourth token tile: its table lookups go out ahead of */ \
+            /* the B reads, the arithmetic sits among the tile's MFMAs; one DMA piece follows each of the first tiles. */
+#define TG_LUT(C) if (((C) & 3) == 1) lookup8(lbase, wv[(C) >> 2], lf);
+#define TG_MATH(C) if (((C) & 3) == 1) a_fill[(C) >> 2] = scale8(lf, ((C) >> 2) < 2 ? sc0 : sc1);
+#define TG_DMA(C) if ((C) < TG_PIECES) dma_piece(full_tag, (C), b + 1, b + 2);
+#define TG_SB __builtin_amdgcn_sched_barrier(0);
+#if TG_LA == 1
+            TG_SB TG_READ(0)
+            TG_SB TG_LUT(0) TG_READ(1) TG_SB TG_MMA(0) TG_MATH(0) TG_DMA(0)
+            TG_SB TG_LUT(1) TG_READ(2) TG_SB TG_MMA(1) TG_MATH(1) TG_DMA(1)
+            TG_SB TG_LUT(2) TG_READ(3) TG_SB TG_MMA(2) TG_MATH(2) TG_DMA(2)
+            TG_SB TG_LUT(3) TG_READ(4) TG_SB TG_MMA(3) TG_MATH(3) TG_DMA(3)
+            TG_SB TG_LUT(4) TG_READ(5) TG_SB TG_MMA(4) TG_MATH(4) TG_DMA(4)
+            TG_SB TG_LUT(5) TG_READ(6) TG_SB TG_MMA(5) TG_MATH(5) TG_DMA(5)
+            TG_SB TG_LUT(6) TG_READ(7) TG_SB TG_MMA(6) TG_MATH(6) TG_DMA(6)
+            TG_SB TG_LUT(7) TG_READ(8) TG_SB TG_MMA(7) TG_MATH(7) TG_DMA(7)
+            TG_SB TG_LUT(8) TG_READ(9) TG_SB TG_MMA(8) TG_MATH(8) TG_DMA(8)
+            TG_SB TG_LUT(9) TG_READ(10) TG_SB TG_MMA(9) TG_MATH(9) TG_DMA(9)
+            TG_SB TG_LUT(10) TG_READ(11) TG_SB TG_MMA(10) TG_MATH(10) TG_DMA(10)
+            TG_SB TG_LUT(11) TG_READ(12) TG_SB TG_MMA(11) TG_MATH(11) TG_DMA(11)
+            TG_SB TG_LUT(12) TG_READ(13) TG_SB TG_MMA(12) TG_MATH(12) TG_DMA(12)
+            TG_SB TG_LUT(13) TG_READ(14) TG_SB TG_MMA(13) TG_MATH(13) TG_DMA(13)
+            TG_SB TG_LUT(14) TG_READ(15) TG_SB TG_MMA(14) TG_MATH(14) TG_DMA(14)
+            TG_SB TG_LUT(15) TG_SB TG_MMA(15) TG_MATH(15) TG_DMA(15)
             TG_SB
+#elif TG_LA == 2
+            TG_SB TG_READ(0)
+            TG_SB TG_READ(1)
+            TG_SB TG_LUT(0) TG_READ(2) TG_SB TG_MMA(0) TG_MATH(0) TG_DMA(0)
+            TG_SB TG_LUT(1) TG_READ(3) TG_SB TG_MMA(1) TG_MATH(1) TG_DMA(1)
+            TG_SB TG_LUT(2) TG_READ(4) TG_SB TG_MMA(2) TG_MATH(2) TG_DMA(2)
+            TG_SB TG_LUT(3) TG_READ(5) TG_SB TG_MMA(3) TG_MATH(3) TG_DMA(3)
+            TG_SB TG_LUT(4) TG_READ(6) TG_SB TG_MMA(4) TG_MATH(4) TG_DMA(4)
+            TG_SB TG_LUT(5) TG_READ(7) TG_SB TG_MMA(5) TG_MATH(5) TG_DMA(5)
+            TG_SB TG_LUT(6) TG_READ(8) TG_SB TG_MMA(6) TG_MATH(6) TG_DMA(6)
+            TG_SB TG_LUT(7) TG_READ(9) TG_SB TG_MMA(7) TG_MATH(7) TG_DMA(7)
+            TG_SB TG_LUT(8) TG_READ(10) TG_SB TG_MMA(8) TG_MATH(8) TG_DMA(8)
+            TG_SB TG_LUT(9) TG_READ(11) TG_SB TG_MMA(9) TG_MATH(9) TG_DMA(9)
+            TG_SB TG_LUT(10) TG_READ(12) TG_SB TG_MMA(10) TG_MATH(10) TG_DMA(10)
+            TG_SB TG_LUT(11) TG_READ(13) TG_SB TG_MMA(11) TG_MATH(11) TG_DMA(11)
+            TG_SB TG_LUT(12) TG_READ(14) TG_SB TG_MMA(12) TG_MATH(12) TG_DMA(12)
+            TG_SB TG_LUT(13) TG_READ(15) TG_SB TG_MMA(13) TG_MATH(13) TG_DMA(13)
+            TG_SB TG_LUT(14) TG_SB TG_MMA(14) TG_MATH(14) TG_DMA(14)
+            TG_SB TG_LUT(15) TG_SB TG_MMA(15) TG_MATH(15) TG_DMA(15)
+            TG_SB
+#else
+            TG_SB TG_READ(0)
+            TG_SB TG_READ(1)
+            TG_SB TG_READ(2)
+            TG_SB TG_LUT(0) TG_READ(3) TG_SB TG_MMA(0) TG_MATH(0) TG_DMA(0)
+            TG_SB TG_LUT(1) TG_READ(4) TG_SB TG_MMA(1) TG_MATH(1) TG_DMA(1)
+            TG_SB TG_LUT(2) TG_READ(5) TG_SB TG_MMA(2) TG_MATH(2) TG_DMA(2)
+            TG_SB TG_LUT(3) TG_READ(6) TG_SB TG_MMA(3) TG_MATH(3) TG_DMA(3)
+            TG_SB TG_LUT(4) TG_READ(7) TG_SB TG_MMA(4) TG_MATH(4) TG_DMA(4)
+            TG_SB TG_LUT(5) TG_READ(8) TG_SB TG_MMA(5) TG_MATH(5) TG_DMA(5)
+            TG_SB TG_LUT(6) TG_READ(9) TG_SB TG_MMA(6) TG_MATH(6) TG_DMA(6)
+            TG_SB TG_LUT(7) TG_READ(10) TG_SB TG_MMA(7) TG_MATH(7) TG_DMA(7)
+            TG_SB TG_LUT(8) TG_READ(11) TG_SB TG_MMA(8) TG_MATH(8) TG_DMA(8)
+            TG_SB TG_LUT(9) TG_READ(12) TG_SB TG_MMA(9) TG_MATH(9) TG_DMA(9)
+            TG_SB TG_LUT(10) TG_READ(13) TG_SB TG_MMA(10) TG_MATH(10) TG_DMA(10)
+            TG_SB TG_LUT(11) TG_READ(14) TG_SB TG_MMA(11) TG_MATH(11) TG_DMA(11)
+            TG_SB TG_LUT(12) TG_READ(15) TG_SB TG_MMA(12) TG_MATH(12) TG_DMA(12)
+            TG_SB TG_LUT(13) TG_SB TG_MMA(13) TG_MATH(13) TG_DMA(13)
+            TG_SB TG_LUT(14) TG_SB TG_MMA(14) TG_MATH(14) TG_DMA(14)
+            TG_SB TG_LUT(15) TG_SB TG_MMA(15) TG_MATH(15) TG_DMA(15)
+            TG_SB
+#endif
 #undef TG_LUT
-#undef TG_PAIR
 #undef TG_MATH
 #undef TG_DMA
 #undef TG_SB
@@ -317,50 +336,44 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     if (p0 >= NP) {
-        if (ntt == TG_TOKEN_TILES) idle_loop(std::true_type{});
+        if (ntt == TILE_ROWS / 16) idle_loop(std::true_type{});
         else idle_loop(std::false_type{});
         return;
     }
-    if (ntt == TG_TOKEN_TILES) main_loop(std::true_type{});
+    if (ntt == TILE_ROWS / 16) main_loop(std::true_type{});
     else main_loop(std::false_type{});
 
-    // ---- epilogue: accumulator register q of lane (n32, h) is token n32, row (q & 3) + 8 (q >> 2) + 4h of the
-    // 32-row tile; rows 0..15 are the pair's first tile (16p + ..), rows 16..31 its partner (16 (p + NP) + ..)
+    // ---- epilogue: register q of lane (r, g) is token r of the 16-token tile, row 4g + q of the pair's first tile
+    // (accA: row 16p + 4g + q) and of its partner (accB: row 16 (p + NP) + 4g + q)
+    {
+        const int p = p0;
+        float ba[4], bb[4];
 #pragma unroll
-    for (int i = 0; i < TG_RT; i++) {
-        const int p = p0 + i;
-        if (p >= NP) continue;
-        float ba[8], bb[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-            ba[q] = sp.bias ? (float)sp.bias[(int64_t)e * R + 16 * p + row] : 0.f;
-            bb[q] = sp.bias ? (float)sp.bias[(int64_t)e * R + 16 * (p + NP) + row] : 0.f;
+        for (int q = 0; q < 4; q++) {
+            ba[q] = sp.bias ? (float)sp.bias[(int64_t)e * R + 16 * p + 4 * g + q] : 0.f;
+            bb[q] = sp.bias ? (float)sp.bias[(int64_t)e * R + 16 * (p + NP) + 4 * g + q] : 0.f;
         }
 #pragma unroll
-        for (int c = 0; c < TG_TOKEN_TILES; c++) {
-            const int m = 32 * c + n32;
+        for (int c = 0; c < NTT; c++) {
+            const int m = 16 * c + r;
             if (m < mt) {
                 const int64_t orow = pos0 + m;
+                half4_t va, vb;
 #pragma unroll
-                for (int g = 0; g < 2; g++) {   // rows 4h.. and 8 + 4h..
-                    half4_t va, vb;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const float a = acc[i][c][4 * g + q] + ba[4 * g + q], bq = acc[i][c][8 + 4 * g + q] + bb[4 * g + q];
-                        if (MODE == 0) {
-                            va[q] = (half_t)act_pair(a, bq, sp);
-                        } else {
-                            va[q] = (half_t)a;
-                            vb[q] = (half_t)bq;
-                        }
-                    }
+                for (int q = 0; q < 4; q++) {
+                    const float a = accA[c][q] + ba[q], bq = accB[c][q] + bb[q];
                     if (MODE == 0) {
-                        *reinterpret_cast<half4_t*>(outp + orow * (R / 2) + 16 * p + 8 * g + 4 * hh) = va;
+                        va[q] = (half_t)act_pair(a, bq, sp);
                     } else {
-                        *reinterpret_cast<half4_t*>(outp + orow * R + 16 * p + 8 * g + 4 * hh) = va;
-                        *reinterpret_cast<half4_t*>(outp + orow * R + 16 * (p + NP) + 8 * g + 4 * hh) = vb;
+                        va[q] = (half_t)a;
+                        vb[q] = (half_t)bq;
                     }
+                }
+                if (MODE == 0) {
+                    *reinterpret_cast<half4_t*>(outp + orow * (R / 2) + 16 * p + 4 * g) = va;
+                } else {
+                    *reinterpret_cast<half4_t*>(outp + orow * R + 16 * p + 4 * g) = va;
+                    *reinterpret_cast<half4_t*>(outp + orow * R + 16 * (p + NP) + 4 * g) = vb;
                 }
             }
         }
