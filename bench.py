@@ -138,8 +138,8 @@ class DecodeStep:
 
     def pieces(self):
         """The launch sequence of a step as (is_collective, callable) pieces, adjacent kernel-only pieces merged: with
-        experts sharded, a layer is [attention, router, pack] -> dispatch all-to-all -> [unpack, experts] -> combine
-        all-to-all -> [reduce], and the reduce joins the next layer's first piece."""
+        experts sharded, a layer is [attention, router + pack] -> dispatch all-to-all -> [experts, reading the received
+        rows in place] -> combine all-to-all -> [reduce], and the reduce joins the next layer's first piece."""
         lib = self.lib
         seq = []
 
@@ -160,8 +160,7 @@ class DecodeStep:
                     lay["x"], lay["wr"], None, TOPK, *ep.weights, E_local=ep.epr, e_first=0, H=H, FF=FF, ids=lay["ids"],
                     w=lay["w"], workspace=ep.workspace, out=lay["out"], flags=ep.flags))
             else:
-                add(False, lambda lay=lay, ep=ep: (lib.router_topk(lay["x"], lay["wr"], None, TOPK, ids=lay["ids"], w=lay["w"]),
-                                                   ep.pack(lay["x"], lay["ids"], lay["w"])))
+                add(False, lambda lay=lay, ep=ep: ep.route_and_pack(lay["x"], lay["wr"], None, lay["ids"], lay["w"]))
                 add(True, ep.dispatch)
                 add(False, ep.experts)
                 add(True, ep.combine)
@@ -520,6 +519,128 @@ def prefill_leg(lib, main_step, device, tokens, reps=3):
     }
 
 
+def graph_seconds(fn, reps=5):
+    """fn() (library launches on the current stream) captured in one HIP graph; seconds per replay, HIP events."""
+    fn()
+    torch.cuda.synchronize()
+    s_ = torch.cuda.Stream()
+    s_.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s_):
+        fn()
+    torch.cuda.current_stream().wait_stream(s_)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        fn()
+    gr.replay()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        gr.replay()
+        b.record()
+        b.synchronize()
+        ts.append(a.elapsed_time(b) * 1e-3)
+    return median(ts)
+
+
+def rank_of_n_leg(lib, main_step, n_ranks, ctx, device):
+    """What ONE rank of an n_ranks-way expert-parallel job launches per layer, collectives excluded, timed on this GPU:
+    the rank keeps E / n_ranks experts, routes its own `batch` tokens, and runs its experts over the n_ranks * batch token
+    slots of the receive buffer (filled here with the rows n_ranks peers with different tokens would have sent it).  Two
+    launch sequences: the separate kernels (router, pack, unpack, experts, reduce) and the fused forms (router + pack,
+    experts on the rows in place, reduce inside the residual add + RMSNorm).  No collective runs and no other rank
+    exists: this prices the kernels of a rank, not the scaling of the job."""
+    B, N = main_step.batch, n_ranks
+    epr = E // N
+    g = torch.Generator(device=device)
+    g.manual_seed(8)
+    rb = lib.ep_row_bytes(H, TOPK)
+    NT = N * B
+    flags = lib.FLAG_FP16_COMBINE | lib.kernel_choice_flags(NT, TOPK, E)
+    ws = torch.empty(max(256, lib.moe_workspace_bytes(NT, TOPK, H, FF, epr)), dtype=torch.uint8, device=device)
+    send = torch.zeros(N * B * rb, dtype=torch.uint8, device=device)
+    x_all = torch.zeros((NT, H), dtype=torch.float16, device=device)
+    ids_all = torch.empty((NT, TOPK), dtype=torch.int32, device=device)
+    w_all = torch.empty((NT, TOPK), dtype=torch.float32, device=device)
+    partial = torch.empty((NT, H), dtype=torch.float16, device=device)
+    delta = torch.empty((B, H), dtype=torch.float16, device=device)
+    resid = torch.randn((B, H), device=device, generator=g).half()
+    resid_out = torch.empty_like(resid)
+    normed = torch.empty_like(resid)
+    norm_w = torch.ones(H, dtype=torch.float16, device=device)
+    layers = []
+    for lay in main_step.L:
+        part = lambda t: (t[0][:epr], t[1][:epr]) if isinstance(t, tuple) else t[:epr]
+        recv = torch.zeros(N * B * rb, dtype=torch.uint8, device=device)
+        for s_ in range(N):   # peer s_: its own tokens, the same router; this rank is rank 0 and receives chunk 0
+            xs = torch.randn((B, H), device=device, generator=g).half()
+            lib.router_topk_ep_pack(xs, lay["wr"], None, TOPK, N, epr, send, ids=lay["ids"], w=lay["w"])
+            recv.view(N, B * rb)[s_] = send.view(N, B * rb)[0]
+        back = (torch.randn((N, B, H), device=device, generator=g) * 0.1).half()
+        layers.append(dict(lay=lay, recv=recv, back=back,
+                           weights=(lay["w13_q"][:epr], part(lay["w13_a"]), lay["w2_q"][:epr], part(lay["w2_a"]))))
+    hit = float(sum((ly["recv"].view(NT, rb)[:, 2 * H:2 * H + 4].contiguous().view(torch.int32) >= 0).sum().item()
+                    for ly in layers)) / len(layers)
+
+    def attention(lay):
+        lib.paged_attn_decode(lay["q"], lay["kc"], lay["vc"], main_step.block_tables, main_step.ctx_lens, max_ctx=ctx,
+                              scale=D ** -0.5, out=lay["attn_out"])
+
+    def separate(with_norm):
+        for ly in layers:
+            lay = ly["lay"]
+            attention(lay)
+            lib.router_topk(lay["x"], lay["wr"], None, TOPK, ids=lay["ids"], w=lay["w"])
+            lib.ep_pack(lay["x"], lay["ids"], lay["w"], N, epr, send)
+            lib.ep_unpack(ly["recv"], NT, TOPK, H, x_all, ids_all, w_all)
+            lib.moe_nf4_forward(x_all, ids_all, w_all, *ly["weights"], E_local=epr, e_first=0, H=H, FF=FF, workspace=ws,
+                                out=partial, flags=flags)
+            lib.ep_reduce(ly["back"], N, B, H, delta)
+            if with_norm:
+                lib.add_rmsnorm(resid, delta, norm_w, 1e-5, resid_out=resid_out, out=normed)
+
+    def fused(with_norm):
+        for ly in layers:
+            lay = ly["lay"]
+            attention(lay)
+            lib.router_topk_ep_pack(lay["x"], lay["wr"], None, TOPK, N, epr, send, ids=lay["ids"], w=lay["w"])
+            lib.moe_nf4_forward_ep_rows(ly["recv"], NT, TOPK, *ly["weights"], E_local=epr, e_first=0, H=H, FF=FF,
+                                        workspace=ws, out=partial, flags=flags)
+            if with_norm:
+                lib.ep_reduce_add_rmsnorm(ly["back"], N, resid, norm_w, 1e-5, resid_out=resid_out, out=normed)
+            else:
+                lib.ep_reduce(ly["back"], N, B, H, delta)
+
+    def only(fn):
+        def run():
+            for ly in layers:
+                fn(ly)
+        return graph_seconds(run) / len(layers) * 1e6
+
+    us = lambda fn: graph_seconds(fn) / len(layers) * 1e6
+    return {
+        "what": f"kernels of one rank of {N} per layer at bs={B} per rank ({epr} local experts, {NT} token slots of which "
+                f"{hit:.0f} carry a token for this rank), one HIP graph of {len(layers)} layers, collectives excluded; "
+                "no scaling curve is measured here",
+        "us_per_layer": us(lambda: fused(False)), "us_per_layer_separate_kernels": us(lambda: separate(False)),
+        "us_per_layer_with_add_rmsnorm": us(lambda: fused(True)),
+        "us_per_layer_with_add_rmsnorm_separate_kernels": us(lambda: separate(True)),
+        "pieces_us": {
+            "attention": only(lambda ly: attention(ly["lay"])),
+            "router_and_pack": only(lambda ly: lib.router_topk_ep_pack(ly["lay"]["x"], ly["lay"]["wr"], None, TOPK, N, epr, send,
+                                                                      ids=ly["lay"]["ids"], w=ly["lay"]["w"])),
+            "experts_on_rows": only(lambda ly: lib.moe_nf4_forward_ep_rows(ly["recv"], NT, TOPK, *ly["weights"], E_local=epr,
+                                                                           e_first=0, H=H, FF=FF, workspace=ws, out=partial,
+                                                                           flags=flags)),
+            "reduce": only(lambda ly: lib.ep_reduce(ly["back"], N, B, H, delta)),
+            "reduce_add_rmsnorm": only(lambda ly: lib.ep_reduce_add_rmsnorm(ly["back"], N, resid, norm_w, 1e-5,
+                                                                            resid_out=resid_out, out=normed)),
+        },
+    }
+
+
 def dequant_leg(lib, main_step, device, reps=5):
     """The standalone NF4 -> fp16 dequantiser (m355_nf4_dequant, what the reference's dequant_unsloth_expert_cpu computes)
     over the packed bytes of one layer's experts: GB/s against the algorithmic 0.515625 B read + 2 B written per
@@ -609,6 +730,8 @@ def main():
                     help="also time the whole decoder stack over one --prefill-tokens prompt (the decode form of that leg is in the default line)")
     ap.add_argument("--no-full-layer", action="store_true", help="skip the whole-decoder-stack decode leg")
     ap.add_argument("--no-dequant-leg", action="store_true")
+    ap.add_argument("--no-rank-of-8", action="store_true",
+                    help="skip the leg that times the kernels one rank of an 8-way expert-parallel job launches per layer")
     a = ap.parse_args()
     global E, LAYERS
     if a.shape == "120b":
@@ -744,6 +867,8 @@ def main():
                                                for b in (a.batch_per_gpu, 1)])
     if single and a.load_leg:
         attempt("load", lambda: load_leg(device))
+    if single and a.shape == "20b" and not a.no_rank_of_8:
+        attempt("ep_rank_of_8", lambda: rank_of_n_leg(lib, main_step, 8, a.ctx, device))
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -9,9 +9,11 @@ namespace m355 {
 constexpr int NORM_THREADS = 256;
 
 // r = fp16(x + delta) (or x); y = fp16(w * (float(r) * rsqrt(mean(float(r)^2) + eps))).  One workgroup per token.
-// COMBINE: delta is not read but formed here, as the MoE combine step forms it (combine_chunk: same bits), from the
+// DELTA 1: delta is not read but formed here, as the MoE combine step forms it (combine_chunk: same bits), from the
 // expert outputs cy / cinv / cw that a forward called with M355_FLAG_SKIP_COMBINE left in its workspace.
-template <bool COMBINE>
+// DELTA 2: delta is formed as the expert-parallel reduce step forms it: cy holds the ranks' partial rows [k_top ranks]
+// [tokens][H] fp16, summed in fp32 in rank order and rounded to fp16 (ep_reduce_kernel: same bits).
+template <int DELTA>
 __global__ __launch_bounds__(NORM_THREADS) void add_rmsnorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ delta,
                                                                    const half_t* __restrict__ weight, float eps, int H,
                                                                    half_t* __restrict__ resid_out, half_t* __restrict__ y,
@@ -30,8 +32,19 @@ __global__ __launch_bounds__(NORM_THREADS) void add_rmsnorm_kernel(const half_t*
         const int c = tid + u * NORM_THREADS;
         if (c < chunks) {
             half8_t v = xr[c];
-            if constexpr (COMBINE) {
-                v = v + combine_chunk<4>(cy, cinv, cw, t, c, H, k_top, fp16_mode);
+            if constexpr (DELTA == 1) {
+                v = v + combine_chunk<4>(cy, cinv, cw, t, c, H, k_top, fp16_mode, k_top);
+            } else if constexpr (DELTA == 2) {
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int rk = 0; rk < k_top; rk++) {
+                    const half8_t pv = reinterpret_cast<const half8_t*>(cy + ((int64_t)rk * gridDim.x + t) * H)[c];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[j] += (float)pv[j];
+                }
+                half8_t d;
+#pragma unroll
+                for (int j = 0; j < 8; j++) d[j] = (half_t)acc[j];
+                v = v + d;
             } else {
                 if (dr) v = v + dr[c];   // fp16 add, rounded, as the residual tensors are
             }
@@ -126,7 +139,7 @@ extern "C" int m355_add_rmsnorm(const void* x_f16, const void* delta_f16, const 
     if (!aligned(x_f16, 16) || !aligned(weight_f16, 16) || !aligned(y_f16, 16) || (delta_f16 && !aligned(delta_f16, 16)) ||
         (resid_out_f16 && !aligned(resid_out_f16, 16)))
         return fail(-3, "m355_add_rmsnorm: buffers must be 16-byte aligned");
-    add_rmsnorm_kernel<false><<<dim3(T), dim3(NORM_THREADS), 0, (hipStream_t)stream>>>(
+    add_rmsnorm_kernel<0><<<dim3(T), dim3(NORM_THREADS), 0, (hipStream_t)stream>>>(
         (const half_t*)x_f16, (const half_t*)delta_f16, (const half_t*)weight_f16, eps, H, (half_t*)resid_out_f16, (half_t*)y_f16,
         nullptr, nullptr, nullptr, 0, 0);
     M355_LAUNCH_CHECK("add_rmsnorm_kernel");
@@ -147,9 +160,26 @@ extern "C" int m355_moe_combine_add_rmsnorm(const void* moe_workspace, size_t ws
     const MoeWorkspace ws = carve_workspace(const_cast<void*>(moe_workspace), T, k, H, FF, E_local);
     if (ws_bytes < ws.bytes)
         return fail(-6, "m355_moe_combine_add_rmsnorm: the workspace of this forward has %zu bytes, %zu given", ws.bytes, ws_bytes);
-    add_rmsnorm_kernel<true><<<dim3(T), dim3(NORM_THREADS), 0, (hipStream_t)stream>>>(
+    add_rmsnorm_kernel<1><<<dim3(T), dim3(NORM_THREADS), 0, (hipStream_t)stream>>>(
         (const half_t*)x_f16, nullptr, (const half_t*)weight_f16, eps, H, (half_t*)resid_out_f16, (half_t*)y_f16, ws.y, ws.inv, w,
         k, (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0);
+    M355_LAUNCH_CHECK("add_rmsnorm_kernel");
+    return 0;
+}
+
+extern "C" int m355_ep_reduce_add_rmsnorm(const void* recv_f16, int n_ranks, const void* x_f16, const void* weight_f16, float eps,
+                                          int T, int H, void* resid_out_f16, void* y_f16, m355_stream_t stream) {
+    if (T == 0) return 0;
+    if (!recv_f16 || !x_f16 || !weight_f16 || !y_f16) return fail(-1, "m355_ep_reduce_add_rmsnorm: null pointer");
+    if (T < 0 || n_ranks <= 0 || H <= 0 || (H % 8) || H > 8 * NORM_THREADS * 4)
+        return fail(-2, "m355_ep_reduce_add_rmsnorm: unsupported shape n_ranks=%d T=%d H=%d (need H %% 8 == 0, H <= %d)", n_ranks, T, H,
+                    8 * NORM_THREADS * 4);
+    if (!aligned(recv_f16, 16) || !aligned(x_f16, 16) || !aligned(weight_f16, 16) || !aligned(y_f16, 16) ||
+        (resid_out_f16 && !aligned(resid_out_f16, 16)))
+        return fail(-3, "m355_ep_reduce_add_rmsnorm: buffers must be 16-byte aligned");
+    add_rmsnorm_kernel<2><<<dim3(T), dim3(NORM_THREADS), 0, (hipStream_t)stream>>>(
+        (const half_t*)x_f16, nullptr, (const half_t*)weight_f16, eps, H, (half_t*)resid_out_f16, (half_t*)y_f16,
+        (const half_t*)recv_f16, nullptr, nullptr, n_ranks, 0);
     M355_LAUNCH_CHECK("add_rmsnorm_kernel");
     return 0;
 }

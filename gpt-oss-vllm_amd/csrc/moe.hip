@@ -52,7 +52,8 @@ __device__ unsigned long long m355_dbg[512 * 2 * 128];
 constexpr int ROUTE_THREADS = 1024;
 constexpr int ROUTE_MAX_E = 1024;
 
-__global__ __launch_bounds__(ROUTE_THREADS) void moe_route_kernel(const int32_t* __restrict__ ids, int P, int E_local,
+__global__ __launch_bounds__(ROUTE_THREADS) void moe_route_kernel(const int32_t* __restrict__ ids, int ids_stride, int k_top,
+                                                                  int P, int E_local,
                                                                   int e_first, int32_t* __restrict__ n_active,
                                                                   int32_t* __restrict__ offsets,
                                                                   int32_t* __restrict__ active,
@@ -66,8 +67,9 @@ __global__ __launch_bounds__(ROUTE_THREADS) void moe_route_kernel(const int32_t*
     const int tid = threadIdx.x;
     for (int e = tid; e < E_local; e += ROUTE_THREADS) cnt[e] = 0;
     __syncthreads();
+    // pair p = (token p / k_top, pick p % k_top); a token's picks are ids_stride int32 apart from the next token's
     for (int p = tid; p < P; p += ROUTE_THREADS) {
-        const int e = ids[p] - e_first;
+        const int e = ids[(int64_t)(p / k_top) * ids_stride + p % k_top] - e_first;
         if (e >= 0 && e < E_local) atomicAdd(&cnt[e], 1);
     }
     __syncthreads();
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(ROUTE_THREADS) void moe_route_kernel(const int32_t*
     }
     __syncthreads();
     for (int p = tid; p < P; p += ROUTE_THREADS) {
-        const int e = ids[p] - e_first;
+        const int e = ids[(int64_t)(p / k_top) * ids_stride + p % k_top] - e_first;
         int pos = -1;
         if (e >= 0 && e < E_local) {
             pos = atomicAdd(&cur[e], 1);
@@ -187,7 +189,8 @@ __global__ __launch_bounds__(MOE_THREADS) void moe_gemm_kernel(const half_t* __r
                                                                const int32_t* __restrict__ offsets,
                                                                const int32_t* __restrict__ active,
                                                                const int32_t* __restrict__ sorted, int K, int R,
-                                                               int k_top, int mt_rows, half_t* __restrict__ outp) {
+                                                               int k_top, int mt_rows, half_t* __restrict__ outp,
+                                                               int64_t x_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int slot = blockIdx.y;
     if (slot >= *n_active) return;
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(MOE_THREADS) void moe_gemm_kernel(const half_t* __r
                 const int row = idx / cpr, c = idx - row * cpr;
                 const int pos = pos0 + m0 + row;
                 const int64_t src_row = (MODE == 0) ? (int64_t)(sorted[pos] / k_top) : (int64_t)pos;
-                const u32x4_t v = reinterpret_cast<const u32x4_t*>(xin + src_row * K)[c];
+                const u32x4_t v = reinterpret_cast<const u32x4_t*>(xin + src_row * x_stride)[c];
                 *reinterpret_cast<u32x4_t*>(xs + row * XS + c * 16) = v;
             }
         }
@@ -410,6 +413,7 @@ __device__ __forceinline__ void gemm_epilogue1(float sumA, float sumB, half_t* _
 // that follow (down GEMM, combine).
 struct RouteIO {
     const int32_t* ids;
+    int ids_stride;   // int32 between the picks of one token and the next (k: dense)
     int P, E_local, e_first;
     int32_t *n_active, *offsets, *active, *sorted, *inv, *n_tiles, *tile_expert, *tile_m0;
     // INLINE == 2: the launch also computes the router (logits, top-k, softmax) for its few tokens, every workgroup
@@ -585,7 +589,8 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
             // must have returned before any wave starts clearing
             __syncthreads();
         } else {
-            if ((int)threadIdx.x < rio.P) my_e = rio.ids[threadIdx.x] - rio.e_first;
+            if ((int)threadIdx.x < rio.P)
+                my_e = rio.ids[(int64_t)((int)threadIdx.x / k_top) * rio.ids_stride + (int)threadIdx.x % k_top] - rio.e_first;
         }
         if (my_e >= rio.E_local) my_e = -1;
         inline_route(rio, my_e, mt_rows, reinterpret_cast<uint32_t*>(red), rt, threadIdx.x, THREADS);
@@ -819,7 +824,7 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
             _Pragma("unroll") for (int s_ = 0; s_ < NT; s_++) {                                             \
                 const int pos = row0 + min(n + 16 * s_, mt - 1);                                            \
                 const int64_t src_row = (MODE == 0) ? (int64_t)(M355_PAIR_AT(pos) / k_top) : (int64_t)pos;  \
-                const u32x4_t* src = reinterpret_cast<const u32x4_t*>(xin + src_row * K) + 2 * g;           \
+                const u32x4_t* src = reinterpret_cast<const u32x4_t*>(xin + src_row * sp.x_stride) + 2 * g; \
                 _Pragma("unroll") for (int i = 0; i < CH; i++) {                                            \
                     const int bb = min(bq0 + i, blast);                                                     \
                     xb[s_][i][0] = __builtin_bit_cast(half8_t, src[8 * bb]);                                \
@@ -941,11 +946,11 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
 template <int KB>
 __global__ __launch_bounds__(256) void moe_combine_kernel(const half_t* __restrict__ y, const int32_t* __restrict__ inv,
                                                           const float* __restrict__ w, int H, int k_top, int fp16_mode,
-                                                          half_t* __restrict__ out) {
+                                                          half_t* __restrict__ out, int w_stride) {
     const int t = blockIdx.x;
     const int chunks = H / 8;
     for (int c = threadIdx.x; c < chunks; c += blockDim.x)
-        reinterpret_cast<half8_t*>(out + (int64_t)t * H)[c] = combine_chunk<KB>(y, inv, w, t, c, H, k_top, fp16_mode);
+        reinterpret_cast<half8_t*>(out + (int64_t)t * H)[c] = combine_chunk<KB>(y, inv, w, t, c, H, k_top, fp16_mode, w_stride);
 }
 
 static int gemm_lds_bytes(int K, int mt_rows) { return LUT_BYTES + RED_BYTES + mt_rows * (K * 2 + XS_PAD); }
@@ -1066,7 +1071,7 @@ static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, c
     const int mt_gen = mt_rows < fit ? mt_rows : fit;
     if (mt_gen < 1) return fail(-2, "m355_moe_nf4_forward: K = %d is too large for the LDS activation tile", K);
     moe_gemm_kernel<MODE><<<dim3((NP + MOE_PAIRS - 1) / MOE_PAIRS, slots), dim3(MOE_THREADS), gemm_lds_bytes(K, mt_gen), st>>>(
-        xin, wq, wam, ws.n_active, ws.offsets, ws.active, ws.sorted, K, R, k_top, mt_gen, outp);
+        xin, wq, wam, ws.n_active, ws.offsets, ws.active, ws.sorted, K, R, k_top, mt_gen, outp, sp.x_stride);
     M355_LAUNCH_CHECK("moe_gemm_kernel");
     return 0;
 }
@@ -1103,6 +1108,13 @@ struct AbsmaxArg {
     const void* base() const { return f32 ? (const void*)f32 : (const void*)u8; }
 };
 
+// Where the rows of x, ids and w lie: dense arrays (strides H, k, k), or inside wider records.
+struct RowsArg {
+    int64_t x_stride;   // fp16 elements
+    int ids_stride;     // int32
+    int w_stride;       // floats
+};
+
 // The router of the same tokens, when the call is to compute it too: router matrix [E_global][H], bias or null; then
 // `ids` / `w` of moe_forward_impl are outputs.
 struct RouterArg {
@@ -1115,7 +1127,7 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
                             AbsmaxArg a13, const uint8_t* w2_q, AbsmaxArg a2, int E_local, int e_first, int H, int FF,
                             int act_mode, int flags, const void* b13_f16, const void* b2_f16, float alpha, float limit,
                             void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream,
-                            RouterArg router = RouterArg{nullptr, nullptr, 0}) {
+                            RouterArg router = RouterArg{nullptr, nullptr, 0}, RowsArg rows = RowsArg{0, 0, 0}) {
     if (T == 0) return 0;   // an empty batch has no buffers to check
     if (!x_f16 || !ids || !w || !w13_q || !a13.ok() || !w2_q || !a2.ok() || !out_f16)
         return fail(-1, "m355_moe_nf4_forward: null pointer");
@@ -1128,8 +1140,9 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
         return fail(-5, "m355_moe_nf4_forward: act_mode %d not supported", act_mode);
     if ((b13_f16 && !aligned(b13_f16, 8)) || (b2_f16 && !aligned(b2_f16, 8)))
         return fail(-3, "m355_moe_nf4_forward: biases must be 8-byte aligned");
-    const StageParams sp13 = {act_mode, alpha, limit, (const half_t*)b13_f16};
-    const StageParams sp2 = {M355_ACT_SILU_CONCAT, 0.f, 0.f, (const half_t*)b2_f16};
+    if (rows.x_stride == 0) rows = RowsArg{H, k, k};
+    const StageParams sp13 = {act_mode, alpha, limit, (const half_t*)b13_f16, rows.x_stride};
+    const StageParams sp2 = {M355_ACT_SILU_CONCAT, 0.f, 0.f, (const half_t*)b2_f16, FF};
     if ((int64_t)T * k > (int64_t)1 << 24) return fail(-2, "m355_moe_nf4_forward: T*k too large");
     const size_t need = m355_moe_workspace_bytes(T, k, H, FF, E_local);
     if (!workspace || ws_bytes < need) return fail(-6, "m355_moe_nf4_forward: workspace of %zu bytes needed, %zu given", need, ws_bytes);
@@ -1168,11 +1181,11 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
                                       const_cast<float*>(w), nullptr, stream))
             return rc;
     }
-    const RouteIO rio = {ids, P, E_local, e_first, ws.n_active, ws.offsets, ws.active, ws.sorted, ws.inv, ws.n_tiles, ws.tile_expert, ws.tile_m0,
+    const RouteIO rio = {ids, rows.ids_stride, P, E_local, e_first, ws.n_active, ws.offsets, ws.active, ws.sorted, ws.inv, ws.n_tiles, ws.tile_expert, ws.tile_m0,
                          (const half_t*)x_f16, (const half_t*)router.wr, (const half_t*)router.br, H, router.E_global, k,
                          const_cast<int32_t*>(ids), const_cast<float*>(w)};
     if (!(flags & M355_FLAG_SKIP_ROUTE) && !inline_route) {
-        moe_route_kernel<<<dim3(1), dim3(ROUTE_THREADS), 0, st>>>(ids, P, E_local, e_first, ws.n_active, ws.offsets,
+        moe_route_kernel<<<dim3(1), dim3(ROUTE_THREADS), 0, st>>>(ids, rows.ids_stride, k, P, E_local, e_first, ws.n_active, ws.offsets,
                                                                   ws.active, ws.sorted, ws.inv, mt_rows, ws.n_tiles,
                                                                   ws.tile_expert, ws.tile_m0);
         M355_LAUNCH_CHECK("moe_route_kernel");
@@ -1199,7 +1212,7 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
     }
     if (!(flags & M355_FLAG_SKIP_COMBINE)) {
         moe_combine_kernel<4><<<dim3(T), dim3(256), 0, st>>>(ws.y, ws.inv, w, H, k, (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0,
-                                                          (half_t*)out_f16);
+                                                          (half_t*)out_f16, rows.w_stride);
         M355_LAUNCH_CHECK("moe_combine_kernel");
     }
     return 0;
@@ -1244,4 +1257,24 @@ extern "C" int m355_moe_nf4_forward_routed(const void* x_f16, int T, const void*
                             bytes ? AbsmaxArg{nullptr, w2_absmax_u8, w2_table} : AbsmaxArg{w2_absmax, nullptr, nullptr},
                             E_local, e_first, H, FF, act_mode, flags, b13_f16, b2_f16, alpha, limit, workspace, ws_bytes,
                             out_f16, stream, RouterArg{wr_f16, br_f16, E_global});
+}
+
+extern "C" int m355_moe_nf4_forward_ep_rows(const void* rows, int NT, int k, const uint8_t* w13_q, const float* w13_absmax,
+                                            const uint8_t* w13_absmax_u8, const float* w13_table, const uint8_t* w2_q,
+                                            const float* w2_absmax, const uint8_t* w2_absmax_u8, const float* w2_table,
+                                            int E_local, int e_first, int H, int FF, int act_mode, int flags,
+                                            const void* b13_f16, const void* b2_f16, float alpha, float limit, void* workspace,
+                                            size_t ws_bytes, void* out_f16, m355_stream_t stream) {
+    if (NT == 0) return 0;
+    if (!rows) return fail(-1, "m355_moe_nf4_forward_ep_rows: null pointer");
+    if (k <= 0 || H <= 0 || (H % 8)) return fail(-2, "m355_moe_nf4_forward_ep_rows: unsupported shape k=%d H=%d", k, H);
+    if (!aligned(rows, 16)) return fail(-3, "m355_moe_nf4_forward_ep_rows: rows must be 16-byte aligned");
+    const size_t rb = m355_ep_row_bytes(H, k);   // [x: H fp16][ids: k int32][w: k fp32], padded to 16 bytes
+    const unsigned char* base = (const unsigned char*)rows;
+    const bool bytes = w13_absmax == nullptr;
+    return moe_forward_impl(base, NT, (const int32_t*)(base + (size_t)2 * H), (const float*)(base + (size_t)2 * H + 4 * (size_t)k), k, w13_q,
+                            bytes ? AbsmaxArg{nullptr, w13_absmax_u8, w13_table} : AbsmaxArg{w13_absmax, nullptr, nullptr}, w2_q,
+                            bytes ? AbsmaxArg{nullptr, w2_absmax_u8, w2_table} : AbsmaxArg{w2_absmax, nullptr, nullptr},
+                            E_local, e_first, H, FF, act_mode, flags, b13_f16, b2_f16, alpha, limit, workspace, ws_bytes, out_f16,
+                            stream, RouterArg{nullptr, nullptr, 0}, RowsArg{(int64_t)(rb / 2), (int)(rb / 4), (int)(rb / 4)});
 }

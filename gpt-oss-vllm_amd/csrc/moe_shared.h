@@ -48,6 +48,8 @@ struct StageParams {
     int act_mode;            // M355_ACT_* (gate_up stage only)
     float alpha, limit;      // swiglu-oai
     const half_t* bias;
+    int64_t x_stride;        // elements between the rows of the stage's input (the row length, unless the rows sit
+                             // inside wider records, as in the receive buffer of the expert-parallel exchange)
 };
 
 
@@ -58,7 +60,8 @@ struct StageParams {
 // the combine with the residual add and RMSNorm that follow it, so both give the same bits.
 template <int KB>
 __device__ __forceinline__ half8_t combine_chunk(const half_t* __restrict__ y, const int32_t* __restrict__ inv,
-                                                 const float* __restrict__ w, int t, int c, int H, int k_top, int fp16_mode) {
+                                                 const float* __restrict__ w, int t, int c, int H, int k_top, int fp16_mode,
+                                                 int w_stride) {   // floats between the tokens' weight rows (k_top: dense)
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) acc[j] = 0.f;
@@ -70,7 +73,7 @@ __device__ __forceinline__ half8_t combine_chunk(const half_t* __restrict__ y, c
         for (int i = 0; i < KB; i++) {
             const bool in = k0 + i < k_top;
             pos[i] = in ? inv[t * k_top + k0 + i] : -1;
-            wf[i] = in ? w[t * k_top + k0 + i] : 0.f;
+            wf[i] = in ? w[(int64_t)t * w_stride + k0 + i] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < KB; i++)

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(TG_THREADS) void moe_tile_gemm_kernel(
         const int m = 8 * (TG_XI * wave + j) + (lane >> 3);
         const int pos = pos0 + min(m, mt - 1);
         const int64_t src_row = (MODE == 0) ? (int64_t)(sorted[pos] / k_top) : (int64_t)pos;
-        xsrc[j] = xin + src_row * K + (((lane & 7) ^ xkey(m)) << 3);
+        xsrc[j] = xin + src_row * sp.x_stride + (((lane & 7) ^ xkey(m)) << 3);
     }
     // B fragment of K-step t (32 columns: this lane's are 16g + 8t .. + 7), token r of a 16-token tile: chunk 2g + t
     uint32_t boff[2];

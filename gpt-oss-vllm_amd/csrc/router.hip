@@ -8,17 +8,58 @@ namespace m355 {
 
 constexpr int ROUTER_THREADS = 512;
 
+// What the expert-parallel dispatch needs from the router's launch: the rows of the send buffer, one per (destination
+// rank, token), [x: H fp16][ids: k int32][w: k fp32] padded to 16 bytes (m355_ep_row_bytes); a token with no expert on a
+// destination gets ids = -1 there and no payload -- what ep_pack_kernel writes, written here by the workgroup that has
+// just routed the token.
+struct PackArg {
+    unsigned char* send;   // null: no packing
+    int T, n_ranks, epr;
+    size_t row_bytes;
+};
+
 __global__ __launch_bounds__(ROUTER_THREADS) void router_topk_kernel(const half_t* __restrict__ x,
                                                                      const half_t* __restrict__ wr,
                                                                      const half_t* __restrict__ br, int H, int E, int k,
                                                                      int32_t* __restrict__ ids, float* __restrict__ w,
-                                                                     half_t* __restrict__ logits_out) {
+                                                                     half_t* __restrict__ logits_out, PackArg pk) {
     __shared__ float logit[ROUTER_MAX_E];
+    __shared__ int32_t pick_id[32];
+    __shared__ float pick_w[32];
     const int t = blockIdx.x;
     const int wave = threadIdx.x >> 6;
     router_logits_wg<ROUTER_THREADS / 64>(x + (int64_t)t * H, wr, br, H, E, logit, logits_out ? logits_out + (int64_t)t * E : nullptr);
     __syncthreads();
-    if (wave == 0) topk_softmax_wave(logit, E, k, ids + (int64_t)t * k, w + (int64_t)t * k);
+    if (wave == 0) {
+        topk_softmax_wave(logit, E, k, pick_id, pick_w);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int lane = threadIdx.x & 63;
+        if (lane < k) {
+            ids[(int64_t)t * k + lane] = pick_id[lane];
+            w[(int64_t)t * k + lane] = pick_w[lane];
+        }
+    }
+    if (!pk.send) return;
+    __syncthreads();
+    for (int r = 0; r < pk.n_ranks; r++) {
+        const int lo = r * pk.epr, hi = lo + pk.epr;
+        bool hit = false;
+        for (int kk = 0; kk < k; kk++) hit |= (pick_id[kk] >= lo && pick_id[kk] < hi);   // (the same for every thread)
+        unsigned char* dst = pk.send + ((size_t)r * pk.T + t) * pk.row_bytes;
+        int32_t* dids = reinterpret_cast<int32_t*>(dst + (size_t)2 * H);
+        float* dw = reinterpret_cast<float*>(dst + (size_t)2 * H + 4 * (size_t)k);
+        if (!hit) {
+            if ((int)threadIdx.x < k) dids[threadIdx.x] = -1;
+            continue;
+        }
+        const u32x4_t* src = reinterpret_cast<const u32x4_t*>(x + (size_t)t * H);
+        for (int c = threadIdx.x; c < H / 8; c += ROUTER_THREADS) reinterpret_cast<u32x4_t*>(dst)[c] = src[c];
+        if ((int)threadIdx.x < k) {
+            dids[threadIdx.x] = pick_id[threadIdx.x];
+            dw[threadIdx.x] = pick_w[threadIdx.x];
+        }
+    }
 }
 
 // Many tokens (prefill): 16 tokens per workgroup on the matrix cores, so the router matrix is read from L2 once per
@@ -127,8 +168,31 @@ extern "C" int m355_router_topk(const void* x_f16, const void* wr_f16, const voi
         return 0;
     }
     router_topk_kernel<<<dim3(T), dim3(ROUTER_THREADS), 0, (hipStream_t)stream>>>(
-        (const half_t*)x_f16, (const half_t*)wr_f16, (const half_t*)br_f16, H, E, k, ids, w, (half_t*)logits_out_f16);
+        (const half_t*)x_f16, (const half_t*)wr_f16, (const half_t*)br_f16, H, E, k, ids, w, (half_t*)logits_out_f16,
+        PackArg{nullptr, 0, 0, 0, 0});
     M355_LAUNCH_CHECK("m355_router_topk");
+    return 0;
+}
+
+extern "C" int m355_router_topk_ep_pack(const void* x_f16, const void* wr_f16, const void* br_f16, int T, int H, int E, int k,
+                                        int32_t* ids, float* w, int n_ranks, int experts_per_rank, void* send,
+                                        m355_stream_t stream) {
+    if (T == 0) return 0;
+    if (!x_f16 || !wr_f16 || !ids || !w || !send) return fail(-1, "m355_router_topk_ep_pack: null pointer");
+    if (T < 0 || H <= 0 || (H % 8) || E <= 0 || E > ROUTER_MAX_E || k <= 0 || k > 32 || k > E || n_ranks <= 0 ||
+        n_ranks > 65535 || experts_per_rank <= 0)
+        return fail(-2, "m355_router_topk_ep_pack: unsupported shape T=%d H=%d E=%d k=%d n_ranks=%d experts_per_rank=%d", T, H, E, k,
+                    n_ranks, experts_per_rank);
+    if (!aligned(x_f16, 16) || !aligned(wr_f16, 16) || !aligned(send, 16))
+        return fail(-3, "m355_router_topk_ep_pack: x, wr and send must be 16-byte aligned");
+    if (T >= ROUTER_TILE_MIN_T) {   // the 16-tokens-per-workgroup router does not pack: two launches
+        if (int rc = m355_router_topk(x_f16, wr_f16, br_f16, T, H, E, k, ids, w, nullptr, stream)) return rc;
+        return m355_ep_pack(x_f16, ids, w, T, k, H, n_ranks, experts_per_rank, send, stream);
+    }
+    router_topk_kernel<<<dim3(T), dim3(ROUTER_THREADS), 0, (hipStream_t)stream>>>(
+        (const half_t*)x_f16, (const half_t*)wr_f16, (const half_t*)br_f16, H, E, k, ids, w, nullptr,
+        PackArg{(unsigned char*)send, T, n_ranks, experts_per_rank, m355_ep_row_bytes(H, k)});
+    M355_LAUNCH_CHECK("m355_router_topk_ep_pack");
     return 0;
 }
 

@@ -28,7 +28,7 @@ EXPORTS = (
     "m355_add_rmsnorm", "m355_rope_kv_write", "m355_linear_f16", "m355_paged_attn_decode_ex",
     "m355_repack_nf4_ex", "m355_moe_nf4_forward_ex", "m355_moe_nf4_forward_q8", "m355_repack_absmax_u8",
     "m355_moe_nf4_forward_routed", "m355_attn_prefill", "m355_moe_combine_add_rmsnorm", "m355_init",
-    "m355_moe_nf4_forward_static",
+    "m355_moe_nf4_forward_static", "m355_router_topk_ep_pack", "m355_moe_nf4_forward_ep_rows", "m355_ep_reduce_add_rmsnorm",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -87,6 +87,13 @@ def load() -> ctypes.CDLL:
     L.m355_paged_attn_workspace_bytes.restype = sz
     L.m355_ep_row_bytes.argtypes = [i32, i32]
     L.m355_ep_row_bytes.restype = sz
+    L.m355_router_topk_ep_pack.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp]
+    L.m355_router_topk_ep_pack.restype = i32
+    L.m355_moe_nf4_forward_ep_rows.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
+                                               vp, vp, f32, f32, vp, sz, vp, vp]
+    L.m355_moe_nf4_forward_ep_rows.restype = i32
+    L.m355_ep_reduce_add_rmsnorm.argtypes = [vp, i32, vp, vp, f32, i32, i32, vp, vp, vp]
+    L.m355_ep_reduce_add_rmsnorm.restype = i32
     L.m355_ep_pack.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, vp, vp]
     L.m355_ep_unpack.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp]
     L.m355_ep_reduce.argtypes = [vp, i32, i32, i32, vp, vp]
@@ -406,6 +413,68 @@ def ep_pack(x, ids, w, n_ranks: int, experts_per_rank: int, send: torch.Tensor):
                                T, k, H, n_ranks, experts_per_rank, _dev(send, torch.uint8, "send"), _stream()),
            "m355_ep_pack")
     return send
+
+
+def router_topk_ep_pack(x: torch.Tensor, wr: torch.Tensor, br: Optional[torch.Tensor], k: int, n_ranks: int,
+                        experts_per_rank: int, send: torch.Tensor, ids: Optional[torch.Tensor] = None,
+                        w: Optional[torch.Tensor] = None):
+    """router_topk and ep_pack in one launch.  Returns (ids, w); `send` [n_ranks, T, row_bytes] is filled.
+    m355_router_topk_ep_pack."""
+    T, H = x.shape
+    E = wr.shape[0]
+    if ids is None:
+        ids = torch.empty((T, k), dtype=torch.int32, device=x.device)
+    if w is None:
+        w = torch.empty((T, k), dtype=torch.float32, device=x.device)
+    if send.numel() != n_ranks * T * ep_row_bytes(H, k):
+        raise ValueError("router_topk_ep_pack: send buffer has the wrong size")
+    _check(load().m355_router_topk_ep_pack(
+        _dev(x, torch.float16, "x"), _dev(wr, torch.float16, "wr"), None if br is None else _dev(br, torch.float16, "br"), T, H, E, k,
+        _dev(ids, torch.int32, "ids"), _dev(w, torch.float32, "w"), n_ranks, experts_per_rank, _dev(send, torch.uint8, "send"),
+        _stream()), "m355_router_topk_ep_pack")
+    return ids, w
+
+
+def moe_nf4_forward_ep_rows(rows: torch.Tensor, NT: int, k: int, w13_q, w13_absmax, w2_q, w2_absmax, *, E_local: int,
+                            e_first: int, H: int, FF: int, workspace: torch.Tensor, out: torch.Tensor,
+                            act_mode: int = ACT_SILU_CONCAT, flags: int = FLAG_FP16_COMBINE, b13: Optional[torch.Tensor] = None,
+                            b2: Optional[torch.Tensor] = None, alpha: float = 1.702, limit: float = 7.0):
+    """The MoE layer on the NT token slots of an expert-parallel receive buffer, read in place (activations, ids and
+    weights inside the rows).  m355_moe_nf4_forward_ep_rows."""
+    if rows.numel() != NT * ep_row_bytes(H, k):
+        raise ValueError("moe_nf4_forward_ep_rows: rows buffer has the wrong size")
+    if isinstance(w13_absmax, tuple) != isinstance(w2_absmax, tuple):
+        raise ValueError("w13_absmax and w2_absmax must both be fp32 tensors or both (codes, table) pairs")
+    if isinstance(w13_absmax, tuple):
+        (c13, t13), (c2, t2) = w13_absmax, w2_absmax
+        a13 = (None, _dev(c13, torch.uint8, "w13_absmax codes"), _dev(t13, torch.float32, "w13 table"))
+        a2 = (None, _dev(c2, torch.uint8, "w2_absmax codes"), _dev(t2, torch.float32, "w2 table"))
+    else:
+        a13 = (_dev(w13_absmax, torch.float32, "w13_absmax"), None, None)
+        a2 = (_dev(w2_absmax, torch.float32, "w2_absmax"), None, None)
+    _check(load().m355_moe_nf4_forward_ep_rows(
+        _dev(rows, torch.uint8, "rows"), NT, k, _dev(w13_q, torch.uint8, "w13_q"), *a13, _dev(w2_q, torch.uint8, "w2_q"), *a2,
+        E_local, e_first, H, FF, act_mode, flags, None if b13 is None else _dev(b13, torch.float16, "b13"),
+        None if b2 is None else _dev(b2, torch.float16, "b2"), float(alpha), float(limit),
+        _dev(workspace, torch.uint8, "workspace"), workspace.numel(), _dev(out, torch.float16, "out"), _stream()),
+        "m355_moe_nf4_forward_ep_rows")
+    return out
+
+
+def ep_reduce_add_rmsnorm(recv: torch.Tensor, n_ranks: int, x: torch.Tensor, weight: torch.Tensor, eps: float,
+                          resid_out: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    """add_rmsnorm(x, delta) with delta = the sum over ranks of recv [n_ranks, T, H], as ep_reduce forms it.
+    m355_ep_reduce_add_rmsnorm."""
+    T, H = x.shape
+    if recv.numel() != n_ranks * T * H:
+        raise ValueError("ep_reduce_add_rmsnorm: recv buffer has the wrong size")
+    if out is None:
+        out = torch.empty_like(x)
+    _check(load().m355_ep_reduce_add_rmsnorm(
+        _dev(recv, torch.float16, "recv"), n_ranks, _dev(x, torch.float16, "x"), _dev(weight, torch.float16, "weight"), float(eps),
+        T, H, None if resid_out is None else _dev(resid_out, torch.float16, "resid_out"), _dev(out, torch.float16, "out"),
+        _stream()), "m355_ep_reduce_add_rmsnorm")
+    return out
 
 
 def ep_unpack(recv, NT: int, k: int, H: int, x_all, ids_all, w_all):

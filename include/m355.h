@@ -223,7 +223,27 @@ M355_API int m355_paged_attn_decode_ex(const void* q_f16, const void* kcache_f16
  *   m355_ep_unpack  splits received rows [NT][row] into x_all [NT][H], ids_all [NT][k], w_all [NT][k].
  *   m355_ep_reduce  out[t] = sum_r recv[r][t] (fp16 partial rows, fp32 sum in rank order), recv [n_ranks][T][H].
  */
+/*   m355_router_topk_ep_pack   m355_router_topk and m355_ep_pack in one launch: the workgroup that routes a token also
+ *                   writes its rows of the send buffer (same ids, weights and bytes as the two calls).
+ *   m355_moe_nf4_forward_ep_rows   m355_moe_nf4_forward_ex / _q8 (absmax: pass either the fp32 pointers or, with
+ *                   w13_absmax == NULL, the byte form) on the token slots of a receive buffer as they lie there, rows
+ *                   [NT][row]: activations, expert ids and routing weights are read in place (no m355_ep_unpack); a slot
+ *                   whose ids are -1 yields a zero row.
+ *   m355_ep_reduce_add_rmsnorm   m355_ep_reduce followed by m355_add_rmsnorm(x, delta = the reduced rows) in one launch
+ *                   (same bits): the sum over ranks lands in the residual add + RMSNorm that follows the MoE block.
+ */
 M355_API size_t m355_ep_row_bytes(int H, int k);
+M355_API int m355_router_topk_ep_pack(const void* x_f16, const void* wr_f16, const void* br_f16, int T, int H, int E, int k,
+                                      int32_t* ids, float* w, int n_ranks, int experts_per_rank, void* send,
+                                      m355_stream_t stream);
+M355_API int m355_moe_nf4_forward_ep_rows(const void* rows, int NT, int k, const uint8_t* w13_q, const float* w13_absmax,
+                                          const uint8_t* w13_absmax_u8, const float* w13_table, const uint8_t* w2_q,
+                                          const float* w2_absmax, const uint8_t* w2_absmax_u8, const float* w2_table,
+                                          int E_local, int e_first, int H, int FF, int act_mode, int flags,
+                                          const void* b13_f16, const void* b2_f16, float alpha, float limit, void* workspace,
+                                          size_t ws_bytes, void* out_f16, m355_stream_t stream);
+M355_API int m355_ep_reduce_add_rmsnorm(const void* recv_f16, int n_ranks, const void* x_f16, const void* weight_f16, float eps,
+                                        int T, int H, void* resid_out_f16, void* y_f16, m355_stream_t stream);
 M355_API int m355_ep_pack(const void* x_f16, const int32_t* ids, const float* w, int T, int k, int H, int n_ranks,
                           int experts_per_rank, void* send, m355_stream_t stream);
 M355_API int m355_ep_unpack(const void* recv, int NT, int k, int H, void* x_all_f16, int32_t* ids_all, float* w_all,

@@ -56,7 +56,7 @@ class CpuOps:
                 ids_all[t] = -1
                 w_all[t] = 0
 
-    def moe(self, x, ids, w, weights, E_local, e_first, H_, FF_, workspace, out, flags):
+    def moe(self, x, ids, w, weights, E_local, e_first, H_, FF_, workspace, out, flags, **act):
         sl = slice(e_first, e_first + E_local)
         o = self.ref.moe_forward(x.numpy(), np.where(ids.numpy() < 0, 10 ** 6, ids.numpy()).astype(np.int32), w.numpy(),
                                  w13_q=self.layer["w13_q"][sl], w13_absmax=self.layer["w13_absmax"][sl],
