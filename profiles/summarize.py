@@ -16,6 +16,29 @@ shutil.copy(f"{src}/bench_line.json", f"profiles/{tag}_bench_line.json")
 for extra in glob.glob(f"{src}/trace_bs1/*/*kernel_stats.csv"):
     shutil.copy(extra, f"profiles/{tag}_bench_bs1_kernel_stats.csv")
 
+import re
+
+
+def short_name(mangled):
+    """_ZN4m355<len><name>[I<template args>E]... -> name[<args>] with the MoE GEMM kernels' arguments spelled out."""
+    m = re.match(r"_ZN4m355(\d+)", mangled)
+    if not m:
+        return mangled.split("(")[0].replace("m355::", "")
+    ln = int(m.group(1))
+    name = mangled[m.end():m.end() + ln]
+    rest = mangled[m.end() + ln:]
+    args = []
+    if rest.startswith("I"):
+        args = re.findall(r"Li(\d+)E", rest.split("EvPK")[0].split("EvP")[0])
+    name = name.replace("_kernel", "")
+    stage = {"0": "gate_up", "1": "down"}
+    if name == "moe_gemm_stream" and len(args) >= 3:
+        return f"moe_gemm_stream<{stage.get(args[0], args[0])},pairs={args[1]},route={('listed', 'inline', 'inline+router')[int(args[2])]}>"
+    if name in ("moe_tile_gemm", "moe_gemm") and args:
+        return f"{name}<{stage.get(args[0], args[0])}>"
+    return name + (f"<{','.join(args)}>" if args else "")
+
+
 groups = collections.defaultdict(list)
 traces = [("bs=32", trace)] + [("bs=1", t) for t in glob.glob(f"{src}/trace_bs1/*/*kernel_trace.csv")]
 for leg, tr_file in traces:
@@ -23,21 +46,7 @@ for leg, tr_file in traces:
       n = r["Kernel_Name"]
       if "m355" not in n:
           continue
-      short = n.split("(")[0]
-      for a, b in (("_ZN4m35522moe_gemm_stream_kernelILi0E", "moe_gemm_stream<gate_up,pairs="), ("_ZN4m35522moe_gemm_stream_kernelILi1E", "moe_gemm_stream<down,pairs=")):
-          if short.startswith(a):
-              short = b + short[len(a) + 2] + ">"
-      for a, b in (("_ZN4m35520moe_tile_gemm_kernelILi0E", "moe_tile_gemm<gate_up>"), ("_ZN4m35520moe_tile_gemm_kernelILi1E", "moe_tile_gemm<down>")):
-          if short.startswith(a):
-              short = b
-      short = short.replace("_ZN4m35516moe_route_kernelE", "moe_route").replace("_ZN4m35523router_topk_tile_kernelE", "router_topk_tile")
-      short = short.replace("m355::moe_route_kernel", "moe_route").replace("m355::attn_prefill_kernel", "attn_prefill").replace("_ZN4m35519attn_prefill_kernelE", "attn_prefill")
-      if short.startswith("_ZN4m35523router_topk_tile_kernel"):
-          short = "router_topk_tile"
-      short = short.replace("_ZN4m35524paged_attn_decode_kernelE", "paged_attn_decode").replace("_ZN4m35518router_topk_kernelE", "router_topk")
-      if short.startswith("_ZN4m35518moe_combine_kernel"):
-          short = "moe_combine"
-      short = short.split("PK")[0].split("EPK")[0]
+      short = short_name(n)
       key = (leg, short, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Workgroup_Size_X"]), int(r["LDS_Block_Size"]),
              int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]))
       groups[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))

@@ -112,8 +112,9 @@ def test_expert_parallel_exchange_world2():
 
 # ------------------------------------------------------------------------------------------------
 # Two ranks with the real HIP kernels on ONE GPU (the test box has one): RCCL refuses two ranks on one device, so the
-# chunks travel through host memory over gloo; everything else (pack, unpack, sharded experts with e_first != 0,
-# reduce) is the product's device code.
+# chunks travel through host memory over gloo; everything else is the product's device code: pack, sharded experts with
+# e_first != 0 reading the received rows in place, reduce -- and then the same layer again in its fused forms (the router
+# writing the send rows, the reduce inside the residual add + RMSNorm).
 def _gpu_worker(rank, world, port, q):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -148,7 +149,29 @@ def _gpu_worker(rank, world, port, q):
     torch.cuda.synchronize()
     want = ref.moe_forward(x, ids, w, **layer, E_local=Eg, H=Hg, FF=FFg).astype(np.float32)
     err = float(np.abs(out.float().cpu().numpy() - want).max())
-    q.put((rank, err, float(np.abs(want).max())))
+
+    # the fused forms: router + pack in one launch from x and the router matrix, reduce inside add + RMSNorm
+    wr = ref.normal_f16(ref.stream_seed(500), (Eg, Hg), 0.1)
+    resid = ref.normal_f16(ref.stream_seed(600, rank), (Tg, Hg))
+    nw = ref.normal_f16(ref.stream_seed(700), (Hg,))
+    ids2, w2, _ = ref.router_topk(x, wr, None, Kg)
+    ids_d = torch.empty((Tg, Kg), dtype=torch.int32, device=dev)
+    w_d = torch.empty((Tg, Kg), dtype=torch.float32, device=dev)
+    r_d = torch.empty((Tg, Hg), dtype=torch.float16, device=dev)
+    y_d = torch.empty((Tg, Hg), dtype=torch.float16, device=dev)
+    moe.route_and_pack(torch.from_numpy(x).to(dev), torch.from_numpy(wr).to(dev), None, ids_d, w_d)
+    moe.dispatch()
+    moe.experts()
+    moe.combine()
+    moe.finish_add_rmsnorm(torch.from_numpy(resid).to(dev), torch.from_numpy(nw).to(dev), 1e-5, r_d, y_d)
+    torch.cuda.synchronize()
+    assert np.array_equal(ids_d.cpu().numpy(), ids2)
+    want2 = ref.moe_forward(x, ids2, w2, **layer, E_local=Eg, H=Hg, FF=FFg)
+    r_want, y_want = ref.add_rmsnorm(resid, want2, nw, 1e-5)
+    err_r = float(np.abs(r_d.float().cpu().numpy() - r_want.astype(np.float32)).max())
+    err_y = float(np.abs(y_d.float().cpu().numpy() - y_want.astype(np.float32)).max())
+    q.put((rank, err, float(np.abs(want).max()), err_r, float(np.abs(r_want.astype(np.float32)).max()), err_y,
+           float(np.abs(y_want.astype(np.float32)).max())))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -168,6 +191,8 @@ def test_expert_parallel_two_ranks_one_gpu():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, err, mx in res:
+    for rank, err, mx, err_r, mx_r, err_y, mx_y in res:
         # partial rows travel as fp16 and are summed over ranks in fp32: tolerance of the GEMM plus one fp16 rounding
         assert err <= 3e-3 * mx + 1e-5, (rank, err, mx)
+        assert err_r <= 3e-3 * mx_r + 1e-5, (rank, err_r, mx_r)
+        assert err_y <= 4e-3 * mx_y + 1e-5, (rank, err_y, mx_y)
