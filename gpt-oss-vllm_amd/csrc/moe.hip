@@ -381,9 +381,11 @@ __device__ __forceinline__ void gemm_epilogue(float4_t accA, float4_t accB, half
 // One output element of an item: row 16p + `row` of the first tile (sumA) and the same row of the partner tile (sumB) for
 // token row `orow`: h = act(gate, up) (MODE 0) or the two y values (MODE 1), expert e.  Same arithmetic, element by
 // element, as gemm_epilogue.
+// `through` (MODE 1): the two stores go through to memory (device-scope stores), for readers on other compute dies of the
+// same launch.
 template <int MODE>
 __device__ __forceinline__ void gemm_epilogue1(float sumA, float sumB, half_t* __restrict__ outp, int64_t orow, int R, int NP,
-                                               int p, int row, int e, const StageParams& sp) {
+                                               int p, int row, int e, const StageParams& sp, bool through = false) {
     if (sp.bias) {
         sumA += (float)sp.bias[(int64_t)e * R + 16 * p + row];
         sumB += (float)sp.bias[(int64_t)e * R + 16 * (p + NP) + row];
@@ -402,6 +404,9 @@ __device__ __forceinline__ void gemm_epilogue1(float sumA, float sumB, half_t* _
             hv = (half_t)((float)sg * up);
         }
         outp[orow * (R / 2) + 16 * p + row] = hv;
+    } else if (through) {
+        store_device_scope(outp + orow * R + 16 * p + row, (half_t)sumA);
+        store_device_scope(outp + orow * R + 16 * (p + NP) + row, (half_t)sumB);
     } else {
         outp[orow * R + 16 * p + row] = (half_t)sumA;
         outp[orow * R + 16 * (p + NP) + row] = (half_t)sumB;
@@ -543,8 +548,12 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
     const int32_t* __restrict__ n_tiles, const int32_t* __restrict__ tile_expert, const int32_t* __restrict__ tile_m0,
     const int32_t* __restrict__ offsets, const int32_t* __restrict__ sorted, int K, int R, int k_top, int mt_rows,
     half_t* __restrict__ outp, int table_len, RouteIO rio, StageParams sp, const uint8_t* __restrict__ wam8,
-    const float* __restrict__ wtab) {
+    const float* __restrict__ wtab, CombineIO cio) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if constexpr (MODE == 0) {
+        // the column-group counters of the down launch that follows on the stream
+        if (cio.pg_done && blockIdx.x == 0 && (int)threadIdx.x < SYNC_PG_COUNTERS) cio.pg_done[threadIdx.x] = 0;
+    }
 #ifdef M355_EXP_STAMPS
     const unsigned long long dbg_entry = __builtin_amdgcn_s_memtime();
     unsigned long long dbg_pro[4] = {0, 0, 0, 0};
@@ -614,6 +623,13 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
     const int per_wg = (int)((uint32_t)total / gridDim.x), extra_wg = total - per_wg * (int)gridDim.x;
     const int it0 = (int)blockIdx.x * per_wg + min((int)blockIdx.x, extra_wg);
     const int it1 = it0 + per_wg + ((int)blockIdx.x < extra_wg ? 1 : 0);
+    if constexpr (MODE == 1) {
+        if (cio.out && total == 0) {   // no token for any local expert: the combined rows are zero
+            const u32x4_t zero = {0u, 0u, 0u, 0u};
+            for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < cio.T * (R / 8); i += (int)(gridDim.x * blockDim.x))
+                reinterpret_cast<u32x4_t*>(cio.out)[i] = zero;
+        }
+    }
     if (it0 >= it1) return;
 
     const int tid = threadIdx.x;
@@ -892,7 +908,7 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
                 sumA += rbuf[((qq * NT + s_) * 8 + r) * 64 + lane];                                         \
                 sumB += rbuf[((qq * NT + s_) * 8 + 4 + r) * 64 + lane];                                     \
             }                                                                                               \
-            if (live && n + 16 * s_ < mt) gemm_epilogue1<MODE>(sumA, sumB, outp, row0 + n + 16 * s_, R, NP, p, 4 * g + r, e, sp); \
+            if (live && n + 16 * s_ < mt) gemm_epilogue1<MODE>(sumA, sumB, outp, row0 + n + 16 * s_, R, NP, p, 4 * g + r, e, sp, MODE == 1 && cio.out != nullptr); \
         }                                                                                                   \
         pos0 = pos1;                                                                                        \
         pos1 = pos2;                                                                                        \
@@ -923,6 +939,44 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
         if (lane == 0) m355_dbg[((size_t)(blockIdx.x & 511) * 2 + (wave >> 2)) * 128 + 3] = r1_;
     }
 #endif
+    if constexpr (MODE == 1) {
+        if (cio.out) {
+            // The combine of this launch's own output.  The y values were stored through to memory (device-scope
+            // stores); every wave waits for its stores to be acknowledged, the workgroup meets, then one thread per
+            // finished item counts it on its column group (device-scope atomic).  Whoever brings a counter to the number
+            // of token tiles knows that all y values of those columns are in memory, and this workgroup combines them
+            // for every token, reading y with device-scope loads.  Nobody waits for another workgroup, and no cache is
+            // written back or invalidated as a whole.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            int32_t* fin = reinterpret_cast<int32_t*>(red);   // [0]: count, [1..]: column groups this workgroup completed
+            if (tid == 0) fin[0] = 0;
+            __syncthreads();
+            const int n_tt = (int)((uint32_t)total / (uint32_t)NPG);
+            for (int i = it0 + tid; i < it1; i += THREADS) {
+                const int pg_i = i % NPG;
+                const int before = __hip_atomic_fetch_add(cio.pg_done + pg_i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (before == n_tt - 1) fin[1 + atomicAdd(&fin[0], 1)] = pg_i;
+            }
+            __syncthreads();
+            const int n_fin = fin[0];
+            if (n_fin > 0) {
+                // columns of pair p: [16p, 16p + 16) and [16(p + NP), ..): two 8-column chunks each
+                constexpr int JOBS = PAIRS * 4;
+                for (int j = 0; j < n_fin; j++) {
+                    const int pg_c = fin[1 + j];
+                    for (int job = tid; job < cio.T * JOBS; job += THREADS) {
+                        const int t = job / JOBS, wi = job % JOBS;
+                        const int p = pg_c * PAIRS + wi / 4;
+                        if (p >= NP) continue;
+                        const int c = (wi & 2) ? 2 * (p + NP) + (wi & 1) : 2 * p + (wi & 1);
+                        reinterpret_cast<half8_t*>(cio.out + (int64_t)t * R)[c] =
+                            combine_chunk<4, true>(outp, cio.inv, cio.w, t, c, R, k_top, cio.fp16_mode, cio.w_stride);
+                    }
+                }
+            }
+        }
+    }
 #undef M355_ITEM
 #undef M355_TILE_EXPERT
 #undef M355_TILE_M0
@@ -1005,6 +1059,8 @@ int moe_device_init(int dev) {
     return tile_gemm_device_setup_once(dev);
 }
 
+constexpr int FOLD_COMBINE_MAX_PAIRS = 32;   // (token, k) pairs up to which the down launch also combines
+
 // mean (token, k) pairs per local expert from which the tile kernel takes over
 constexpr int TILE_MIN_MEAN_PAIRS = 68;   // measured crossover against the 32-token streaming form on gpt-oss-20b shapes (32 experts: about 540 tokens)
 
@@ -1024,7 +1080,7 @@ static bool can_route_inline(int P, int E_local, int K) {
 template <int MODE, int INLINE>
 static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, const MoeWorkspace& ws, int K, int R,
                        int k_top, int mt_rows, int slots, half_t* outp, int cus, hipStream_t st, const RouteIO& rio,
-                       const StageParams& sp, const uint8_t* wam8, const float* wtab) {
+                       const StageParams& sp, const uint8_t* wam8, const float* wtab, const CombineIO& cio) {
     const int NP = R / 32, NB = K / 64;
     if (NB <= MOE_KPARTS * MOE_CHUNK) {
         // upper bound of sum_e ceil(M_e / mt_rows): with T <= 16 a token tile holds a whole expert (M_e <= T = mt_rows)
@@ -1037,7 +1093,7 @@ static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, c
                 const int items1 = max_tiles * NP;
                 const int grid = items1 < cus ? items1 : cus;
                 moe_gemm_stream_kernel<MODE, 1, 0, WIDE_KP, 2><<<dim3(grid), dim3(WIDE_KP * 64), lds, st>>>(
-                    xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio, sp, wam8, wtab);
+                    xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio, sp, wam8, wtab, cio);
                 M355_LAUNCH_CHECK("moe_gemm_stream_kernel");
                 return 0;
             }
@@ -1051,14 +1107,14 @@ static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, c
             const int lds = stream_lds_bytes(2, INLINE);
             const int grid = items2 < cus ? items2 : cus;
             moe_gemm_stream_kernel<MODE, 2, INLINE><<<dim3(grid), dim3(512), lds, st>>>(
-                xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio, sp, wam8, wtab);
+                xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio, sp, wam8, wtab, cio);
         } else {
             const int lds = stream_lds_bytes(1, INLINE);
             const int per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
             const int items1 = max_tiles * NP;
             const int grid = items1 < per_cu * cus ? items1 : per_cu * cus;
             moe_gemm_stream_kernel<MODE, 1, INLINE><<<dim3(grid), dim3(256), lds, st>>>(
-                xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio, sp, wam8, wtab);
+                xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio, sp, wam8, wtab, cio);
         }
         M355_LAUNCH_CHECK("moe_gemm_stream_kernel");
         return 0;
@@ -1201,15 +1257,30 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
             if (int rc = launch_tile_gemm(1, ws.h, w2_q, w2_absmax, a2.u8, a2.table, ws, FF, H, k, max_tiles, ws.y, sp2, st))
                 return rc;
     }
+#ifdef M355_EXP_NO_FOLD   /* experiment: the combine always as its own launch */
+    const bool fold_combine_off = true;
+#else
+    const bool fold_combine_off = false;
+#endif
+    // The combine step rides in the down launch when both GEMM stages run here as streaming-kernel launches (gate_up clears
+    // the counters the down launch counts on) and the batch is small: the y values then travel through memory as
+    // device-scope 2-byte stores, which costs more than the saved launch from a few dozen (token, k) pairs on (measured:
+    // 2.7 us per layer gained at 4 pairs, 6 us lost at 128).  M355_FLAG_FOLD_COMBINE folds at any size.
+    const bool fold_combine = !fold_combine_off && !tiled && (P <= FOLD_COMBINE_MAX_PAIRS || (flags & M355_FLAG_FOLD_COMBINE)) && H / 64 <= MOE_KPARTS * MOE_CHUNK && FF / 64 <= MOE_KPARTS * MOE_CHUNK && H / 32 <= 2 * SYNC_PG_COUNTERS &&
+                              !(flags & (M355_FLAG_SKIP_GATE_UP | M355_FLAG_SKIP_DOWN | M355_FLAG_SKIP_COMBINE | M355_FLAG_SEPARATE_COMBINE));
+    const CombineIO cio_gu = {nullptr, nullptr, nullptr, 0, 0, 0, fold_combine ? ws.pg_done : nullptr};
+    const CombineIO cio_dn = {fold_combine ? (half_t*)out_f16 : nullptr, ws.inv, w, rows.w_stride, T,
+                              (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0, ws.pg_done};
     if (!tiled && !(flags & M355_FLAG_SKIP_GATE_UP)) {
-        if (int rc = fuse_router    ? launch_gemm<0, 2>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table)
-                     : inline_route ? launch_gemm<0, 1>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table)
-                                    : launch_gemm<0, 0>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table))
+        if (int rc = fuse_router    ? launch_gemm<0, 2>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table, cio_gu)
+                     : inline_route ? launch_gemm<0, 1>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table, cio_gu)
+                                    : launch_gemm<0, 0>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table, cio_gu))
             return rc;
     }
     if (!tiled && !(flags & M355_FLAG_SKIP_DOWN)) {
-        if (int rc = launch_gemm<1, 0>(ws.h, w2_q, w2_absmax, ws, FF, H, k, mt_rows, slots, ws.y, cus, st, rio, sp2, a2.u8, a2.table)) return rc;
+        if (int rc = launch_gemm<1, 0>(ws.h, w2_q, w2_absmax, ws, FF, H, k, mt_rows, slots, ws.y, cus, st, rio, sp2, a2.u8, a2.table, cio_dn)) return rc;
     }
+    if (fold_combine) return 0;
     if (!(flags & M355_FLAG_SKIP_COMBINE)) {
         moe_combine_kernel<4><<<dim3(T), dim3(256), 0, st>>>(ws.y, ws.inv, w, H, k, (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0,
                                                           (half_t*)out_f16, rows.w_stride);

@@ -18,15 +18,20 @@ struct MoeWorkspace {
     int32_t* tile_m0;      // [P + E_local]  first token (within the expert) of the tile
     half_t* h;           // [P][FF]
     half_t* y;           // [P][H]
+    int32_t* pg_done;    // [SYNC_PG_COUNTERS]  finished token tiles per group of output columns of the down stage (the
+                         //   gate_up launch clears them, the down launch counts: see CombineIO)
     size_t bytes;
     int max_pairs;       // P
 };
+
+constexpr int SYNC_PG_COUNTERS = 128;   // >= groups of output columns of the down stage (H <= 3072: at most 96)
 
 __host__ inline MoeWorkspace carve_workspace(void* base, int T, int k, int H, int FF, int E_local) {
     const size_t P = (size_t)T * k;
     size_t off = 0;
     char* b = reinterpret_cast<char*>(base);
     MoeWorkspace w;
+    w.pg_done = reinterpret_cast<int32_t*>(b + off);  off = align_up(off + 4 * (size_t)SYNC_PG_COUNTERS, 256);
     w.n_active = reinterpret_cast<int32_t*>(b + off); off = align_up(off + 4, 256);
     w.offsets = reinterpret_cast<int32_t*>(b + off);  off = align_up(off + 4 * (size_t)(E_local + 1), 256);
     w.active = reinterpret_cast<int32_t*>(b + off);   off = align_up(off + 4 * (size_t)E_local, 256);
@@ -53,12 +58,41 @@ struct StageParams {
 };
 
 
+// Device-scope accesses: the store is performed at memory and the load is served from there, whichever compute die's L2
+// the address may sit in -- what workgroups of one launch need to hand data to each other across dies without writing
+// back or invalidating whole caches.
+__device__ __forceinline__ void store_device_scope(half_t* p, half_t v) {
+    __hip_atomic_store(reinterpret_cast<unsigned short*>(p), __builtin_bit_cast(unsigned short, v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ half8_t load_half8_device_scope(const half_t* p) {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    unsigned long long v[2];
+    v[0] = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v[1] = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_bit_cast(half8_t, v);
+}
+
+// The combine step folded into the down stage's launch (streaming kernel).  A work item of that launch is (token tile,
+// group of output columns); when the last token tile of a column group has been written, every y value those columns of
+// `out` depend on exists, and the workgroup that finished last combines them.  Completion is counted per column group in
+// pg_done, which the gate_up launch of the same forward call has cleared (it precedes the down launch on the stream).
+// out == null: not folded (the combine runs as its own launch, or the caller combines).
+struct CombineIO {
+    half_t* out;             // [T][H]
+    const int32_t* inv;      // pair index -> row of y, -1: expert not local
+    const float* w;          // routing weights, w_stride floats per token
+    int w_stride, T, fp16_mode;
+    int32_t* pg_done;        // gate_up: cleared when non-null; down: counted
+};
+
 // The combine step for 8 columns of one token: sum over the token's local pairs, in k order.  FP16 mode rounds as the
 // reference's fp16 tensors do: w -> fp16, product -> fp16, running sum -> fp16.  The pairs are taken KB at a time: their
 // positions and weights are requested together, then their y rows together, and only the arithmetic runs in k order, so a
 // batch costs two memory round trips instead of two per pair.  Shared by the combine kernel and by the kernel that fuses
 // the combine with the residual add and RMSNorm that follow it, so both give the same bits.
-template <int KB>
+// THROUGH: y is read with device-scope loads (it was written by other workgroups of the same launch).
+template <int KB, bool THROUGH = false>
 __device__ __forceinline__ half8_t combine_chunk(const half_t* __restrict__ y, const int32_t* __restrict__ inv,
                                                  const float* __restrict__ w, int t, int c, int H, int k_top, int fp16_mode,
                                                  int w_stride) {   // floats between the tokens' weight rows (k_top: dense)
@@ -77,7 +111,10 @@ __device__ __forceinline__ half8_t combine_chunk(const half_t* __restrict__ y, c
         }
 #pragma unroll
         for (int i = 0; i < KB; i++)
-            if (pos[i] >= 0) yv[i] = reinterpret_cast<const half8_t*>(y + (int64_t)pos[i] * H)[c];
+            if (pos[i] >= 0) {
+                if constexpr (THROUGH) yv[i] = load_half8_device_scope(y + (int64_t)pos[i] * H + 8 * c);
+                else yv[i] = reinterpret_cast<const half8_t*>(y + (int64_t)pos[i] * H)[c];
+            }
 #pragma unroll
         for (int i = 0; i < KB; i++) {
             if (pos[i] < 0) continue;

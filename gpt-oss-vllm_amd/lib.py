@@ -18,7 +18,8 @@ ACT_SILU_CONCAT = 0
 ACT_SWIGLU_OAI = 1
 FLAG_FP16_COMBINE = 1
 FLAG_SKIP_ROUTE, FLAG_SKIP_GATE_UP, FLAG_SKIP_DOWN, FLAG_SKIP_COMBINE = 0x100, 0x200, 0x400, 0x800
-FLAG_FORCE_STREAM, FLAG_FORCE_TILE, FLAG_STREAM_WIDE = 0x1000, 0x2000, 0x4000
+FLAG_FORCE_STREAM, FLAG_FORCE_TILE, FLAG_STREAM_WIDE, FLAG_SEPARATE_COMBINE = 0x1000, 0x2000, 0x4000, 0x8000
+FLAG_FOLD_COMBINE = 0x10000
 
 # every symbol include/m355.h declares
 EXPORTS = (

@@ -51,6 +51,12 @@ typedef void* m355_stream_t; /* a hipStream_t (NULL = the default stream) */
    token slots of all ranks but only its share of the pairs, so there the caller, who knows the global expert count,
    makes the choice. */
 #define M355_FLAG_STREAM_WIDE 0x4000
+/* The combine step (out[t] = sum over k of w * y) rides in the down stage's launch when the streaming kernel runs both
+   stages on a small batch (up to 32 (token, k) pairs); SEPARATE_COMBINE makes it its own launch there too, as it is for
+   larger batches and after the tile kernel; FOLD_COMBINE folds it at any batch size the streaming kernel takes.  Same
+   bits every way. */
+#define M355_FLAG_SEPARATE_COMBINE 0x8000
+#define M355_FLAG_FOLD_COMBINE 0x10000
 
 M355_API int m355_version(void);
 M355_API const char* m355_last_error(void);
