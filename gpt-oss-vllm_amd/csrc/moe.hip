@@ -556,7 +556,7 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
     }
 #ifdef M355_EXP_STAMPS
     const unsigned long long dbg_entry = __builtin_amdgcn_s_memtime();
-    unsigned long long dbg_pro[4] = {0, 0, 0, 0};
+    unsigned long long dbg_pro[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define M355_PRO_STAMP(K) dbg_pro[K] = __builtin_amdgcn_s_memtime();
 #else
 #define M355_PRO_STAMP(K)
@@ -584,6 +584,7 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
             int32_t* il = reinterpret_cast<int32_t*>(wl + rio.P);
             for (int t = 0; t < Tn; t++)
                 router_logits_wg<PAIRS * KP>(rio.r_x + (int64_t)t * rio.r_H, rio.r_wr, rio.r_br, rio.r_H, rio.r_E, lg + t * rio.r_E, nullptr);
+            M355_PRO_STAMP(3)   /* router logits computed */
             __syncthreads();
             for (int t = threadIdx.x >> 6; t < Tn; t += PAIRS * KP) topk_softmax_wave(lg + t * rio.r_E, rio.r_E, rio.r_k, il + t * rio.r_k, wl + t * rio.r_k);
             __syncthreads();
@@ -631,6 +632,7 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
         }
     }
     if (it0 >= it1) return;
+    M355_PRO_STAMP(4)   /* item range known */
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -729,6 +731,7 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
     pos1 = (it0 + 1 < it1) ? step(pos0) : pos0;
     pos2 = (it0 + 2 < it1) ? step(pos1) : pos1;
     const int tt_first = pos0.tt, tt_second = pos1.tt;
+    M355_PRO_STAMP(5)   /* first item places known */
     uint32_t cA1 = 0, cB1 = 0;
     M355_ADDR_OF(pos0)
     if (wam8) {
@@ -743,6 +746,7 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
     } else {
         M355_SCALES_OF(pos0, pos1, false)
     }
+    M355_PRO_STAMP(6)   /* codes and tables requested */
 #pragma unroll
     for (int i = 0; i < CH; i++) M355_LOAD(i)
     M355_PRO_STAMP(1)   /* first loads issued */
@@ -923,7 +927,8 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
         if (lane == 0) {
             unsigned long long* d_ = m355_dbg + ((size_t)(blockIdx.x & 511) * 2 + (wave >> 2)) * 128;
             d_[0] = dbg_entry; d_[1] = r0_; d_[2] = (unsigned long long)(it1 - it0); d_[3] = 0; d_[4] = t0_;
-            d_[124] = dbg_pro[0]; d_[125] = dbg_pro[1]; d_[126] = dbg_pro[2];
+            d_[124] = dbg_pro[0]; d_[125] = dbg_pro[1]; d_[126] = dbg_pro[2]; d_[127] = dbg_pro[3];
+            d_[121] = dbg_pro[4]; d_[122] = dbg_pro[5]; d_[123] = dbg_pro[6];
         }
         dbg_n = 1;
     }
