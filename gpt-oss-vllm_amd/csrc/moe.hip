@@ -1225,7 +1225,8 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
     bool wide = !tiled && T > MOE_MAX_MT && H / 64 <= MOE_KPARTS * MOE_CHUNK && FF / 64 <= MOE_KPARTS * MOE_CHUNK;
     if (wide && !(flags & M355_FLAG_STREAM_WIDE))
         wide = !(flags & M355_FLAG_FORCE_STREAM) && (int64_t)P >= (int64_t)WIDE_MIN_MEAN_PAIRS * E_local;
-    const int mt_rows = tiled ? TILE_ROWS : wide ? WIDE_MT : (T < MOE_MAX_MT ? T : MOE_MAX_MT);
+    const int tile_rows = tile_gemm_rows();
+    const int mt_rows = tiled ? tile_rows : wide ? WIDE_MT : (T < MOE_MAX_MT ? T : MOE_MAX_MT);
     const int slots = P < E_local ? P : E_local;
 
     int dev = 0, cus = 0;
@@ -1253,7 +1254,7 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
     }
     if (tiled) {
         if (int rc = tile_gemm_device_setup_once(dev)) return rc;
-        const int max_tiles = (slots + P / TILE_ROWS < P) ? slots + P / TILE_ROWS : P;   // >= sum_e ceil(M_e / TILE_ROWS)
+        const int max_tiles = (slots + P / tile_rows < P) ? slots + P / tile_rows : P;   // >= sum_e ceil(M_e / tile_rows)
         if (!(flags & M355_FLAG_SKIP_GATE_UP))
             if (int rc = launch_tile_gemm(0, (const half_t*)x_f16, w13_q, w13_absmax, a13.u8, a13.table, ws, H, 2 * FF, k,
                                           max_tiles, ws.h, sp13, st))

@@ -138,12 +138,12 @@ __device__ __forceinline__ half8_t combine_chunk(const half_t* __restrict__ y, c
 }
 
 // Token tiles of the large-M kernel: up to this many rows of one expert share one pass over the expert's weights.
-constexpr int TILE_ROWS = 256;
+int tile_gemm_rows();
 
 // Large-M fused dequant GEMM (moe_tile.hip).  mode 0: h = act(W13 x) from x [T][K] gathered through `sorted`;
 // mode 1: y = W2 h from h [P][K] in sorted order.  W is [R][K] per expert in tile order; absmax fp32 (wam) or code
 // bytes + per-expert table (wam8, wtab).  The routing lists in `ws` must have been built with token tiles of
-// TILE_ROWS rows; `max_tiles` bounds their number.
+// tile_gemm_rows() rows; `max_tiles` bounds their number.
 int launch_tile_gemm(int mode, const half_t* xin, const uint8_t* wq, const float* wam, const uint8_t* wam8,
                      const float* wtab, const MoeWorkspace& ws, int K, int R, int k_top, int max_tiles, half_t* outp,
                      const StageParams& sp, hipStream_t st);
