@@ -286,8 +286,6 @@ __global__ __launch_bounds__(MOE_THREADS) void moe_gemm_kernel(const half_t* __r
             M355_BLOCK(6) M355_BLOCK(7) M355_BLOCK(8) M355_BLOCK(9) M355_BLOCK(10) M355_BLOCK(11)
 #undef M355_BLOCK
 #undef M355_FIRST_FETCH
-#undef M355_STAGGER
-#undef M355_SCHED_FENCE
         }
 
         // sum the K-parts: parts 1..3 park their tiles in LDS, part 0 adds them and writes the result
@@ -813,18 +811,8 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
 #define M355_BLOCK(I, NEXT, LOAD) M355_FETCH(I, LOAD) M355_MFMA(I) M355_SCALE(I)
 #define M355_FIRST_FETCH(LOAD)
 #else
-#define M355_BLOCK(I, NEXT, LOAD) NEXT M355_SCHED_FENCE M355_MFMA(I) M355_SCALE(I)
+#define M355_BLOCK(I, NEXT, LOAD) NEXT M355_MFMA(I) M355_SCALE(I)
 #define M355_FIRST_FETCH(LOAD) M355_FETCH(0, LOAD)
-#endif
-#ifdef M355_EXP_STAGGER   /* experiment: the second half of the waves starts every item a little later than its SIMD partners */
-#define M355_STAGGER if (wave >= THREADS / 128) __builtin_amdgcn_s_sleep(M355_EXP_STAGGER);
-#else
-#define M355_STAGGER
-#endif
-#ifdef M355_EXP_SCHED_FENCE
-#define M355_SCHED_FENCE __builtin_amdgcn_sched_barrier(0);
-#else
-#define M355_SCHED_FENCE
 #endif
 
     // One work item.  LOAD is M355_LOAD while another item follows in this workgroup's range (the ring then refills
@@ -875,7 +863,6 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
         half8_t fa[2][4];                                                                                   \
         float4_t pa[NT], pb[NT];                                                                            \
         M355_STAMP()                                                                                        \
-        M355_STAGGER                                                                                        \
         M355_FIRST_FETCH(LOAD)                                                                              \
         M355_BLOCK(0, M355_FETCH(1, LOAD), LOAD) M355_BLOCK(1, M355_FETCH(2, LOAD), LOAD)                   \
         M355_BLOCK(2, M355_FETCH(3, LOAD), LOAD) M355_BLOCK(3, M355_FETCH(4, LOAD), LOAD)                   \
@@ -989,8 +976,6 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
 #undef M355_PAIR_AT
 #undef M355_BLOCK
 #undef M355_FIRST_FETCH
-#undef M355_STAGGER
-#undef M355_SCHED_FENCE
 #undef M355_SCALE
 #undef M355_MFMA
 #undef M355_FETCH
@@ -1103,12 +1088,7 @@ static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, c
                 return 0;
             }
         }
-#ifdef M355_EXP_PAIRS1_SMALL   /* experiment: single-pair items, two 4-wave workgroups per CU, for a handful of tokens */
-        const bool small_batch = ws.max_pairs / k_top <= 8;
-#else
-        const bool small_batch = false;
-#endif
-        if (2 * items2 >= cus && !small_batch) {   // 8-wave workgroups unless even those would leave most CUs idle
+        if (2 * items2 >= cus) {   // 8-wave workgroups unless even those would leave most CUs idle
             const int lds = stream_lds_bytes(2, INLINE);
             const int grid = items2 < cus ? items2 : cus;
             moe_gemm_stream_kernel<MODE, 2, INLINE><<<dim3(grid), dim3(512), lds, st>>>(
@@ -1263,16 +1243,11 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
             if (int rc = launch_tile_gemm(1, ws.h, w2_q, w2_absmax, a2.u8, a2.table, ws, FF, H, k, max_tiles, ws.y, sp2, st))
                 return rc;
     }
-#ifdef M355_EXP_NO_FOLD   /* experiment: the combine always as its own launch */
-    const bool fold_combine_off = true;
-#else
-    const bool fold_combine_off = false;
-#endif
     // The combine step rides in the down launch when both GEMM stages run here as streaming-kernel launches (gate_up clears
     // the counters the down launch counts on) and the batch is small: the y values then travel through memory as
     // device-scope 2-byte stores, which costs more than the saved launch from a few dozen (token, k) pairs on (measured:
     // 2.7 us per layer gained at 4 pairs, 6 us lost at 128).  M355_FLAG_FOLD_COMBINE folds at any size.
-    const bool fold_combine = !fold_combine_off && !tiled && (P <= FOLD_COMBINE_MAX_PAIRS || (flags & M355_FLAG_FOLD_COMBINE)) && H / 64 <= MOE_KPARTS * MOE_CHUNK && FF / 64 <= MOE_KPARTS * MOE_CHUNK && H / 32 <= 2 * SYNC_PG_COUNTERS &&
+    const bool fold_combine = !tiled && (P <= FOLD_COMBINE_MAX_PAIRS || (flags & M355_FLAG_FOLD_COMBINE)) && H / 64 <= MOE_KPARTS * MOE_CHUNK && FF / 64 <= MOE_KPARTS * MOE_CHUNK && H / 32 <= 2 * SYNC_PG_COUNTERS &&
                               !(flags & (M355_FLAG_SKIP_GATE_UP | M355_FLAG_SKIP_DOWN | M355_FLAG_SKIP_COMBINE | M355_FLAG_SEPARATE_COMBINE));
     const CombineIO cio_gu = {nullptr, nullptr, nullptr, 0, 0, 0, fold_combine ? ws.pg_done : nullptr};
     const CombineIO cio_dn = {fold_combine ? (half_t*)out_f16 : nullptr, ws.inv, w, rows.w_stride, T,
