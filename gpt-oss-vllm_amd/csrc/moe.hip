@@ -1052,7 +1052,7 @@ int moe_device_init(int dev) {
 constexpr int FOLD_COMBINE_MAX_PAIRS = 32;   // (token, k) pairs up to which the down launch also combines
 
 // mean (token, k) pairs per local expert from which the tile kernel takes over
-constexpr int TILE_MIN_MEAN_PAIRS = 68;   // measured crossover against the 32-token streaming form on gpt-oss-20b shapes (32 experts: about 540 tokens)
+constexpr int TILE_MIN_MEAN_PAIRS = 80;   // measured crossover against the 32-token streaming form on gpt-oss-20b shapes (32 experts: 640 tokens)
 
 constexpr int ABSMAX_TABLE_SLOTS_BYTES = 4 * 256 * 4;   // four experts' absmax tables (byte form)
 static int stream_lds_bytes(int pairs, int inline_route, int kparts = MOE_KPARTS, int token_sets = 1) {   // (activations live in registers)

@@ -254,7 +254,7 @@ def moe_workspace_bytes(T: int, k: int, H: int, FF: int, E_local: int) -> int:
     return int(load().m355_moe_workspace_bytes(T, k, H, FF, E_local))
 
 
-TILE_MIN_MEAN_PAIRS = 68   # the library's own crossover between its two MoE GEMM kernels (csrc/moe.hip)
+TILE_MIN_MEAN_PAIRS = 80   # the library's own crossover between its two MoE GEMM kernels (csrc/moe.hip)
 WIDE_MIN_MEAN_PAIRS = 16   # ... and, within the streaming kernel, between token tiles of 16 and of 32
 
 
