@@ -3,6 +3,7 @@
 // Arithmetic follows transformers' modeling_gpt_oss.py (GptOssRMSNorm.forward, _apply_rotary_emb) operation by
 // operation, with fp16 tensors where that code has model-dtype tensors, so every intermediate rounds where theirs does.
 #include "moe_shared.h"
+#include "router_shared.h"
 
 namespace m355 {
 
@@ -13,14 +14,15 @@ constexpr int NORM_THREADS = 256;
 // expert outputs cy / cinv / cw that a forward called with M355_FLAG_SKIP_COMBINE left in its workspace.
 // DELTA 2: delta is formed as the expert-parallel reduce step forms it: cy holds the ranks' partial rows [k_top ranks]
 // [tokens][H] fp16, summed in fp32 in rank order and rounded to fp16 (ep_reduce_kernel: same bits).
+// The work of one token's row, by the first NORM_THREADS threads of the workgroup (`active`; the others only keep the
+// barrier).  y_copy (optional, LDS): the normalised row for a consumer in the same workgroup.
 template <int DELTA>
-__global__ __launch_bounds__(NORM_THREADS) void add_rmsnorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ delta,
-                                                                   const half_t* __restrict__ weight, float eps, int H,
-                                                                   half_t* __restrict__ resid_out, half_t* __restrict__ y,
-                                                                   const half_t* __restrict__ cy, const int32_t* __restrict__ cinv,
-                                                                   const float* __restrict__ cw, int k_top, int fp16_mode) {
-    __shared__ float part[NORM_THREADS / 64];
-    const int t = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void add_rmsnorm_row(bool active, int t, int tid, const half_t* __restrict__ x,
+                                                const half_t* __restrict__ delta, const half_t* __restrict__ weight, float eps,
+                                                int H, half_t* __restrict__ resid_out, half_t* __restrict__ y,
+                                                const half_t* __restrict__ cy, const int32_t* __restrict__ cinv,
+                                                const float* __restrict__ cw, int k_top, int fp16_mode, float* part,
+                                                half_t* y_copy) {
     const int chunks = H / 8;
     const half8_t* xr = reinterpret_cast<const half8_t*>(x + (int64_t)t * H);
     const half8_t* dr = delta ? reinterpret_cast<const half8_t*>(delta + (int64_t)t * H) : nullptr;
@@ -30,7 +32,7 @@ __global__ __launch_bounds__(NORM_THREADS) void add_rmsnorm_kernel(const half_t*
 #pragma unroll
     for (int u = 0; u < MAXC; u++) {
         const int c = tid + u * NORM_THREADS;
-        if (c < chunks) {
+        if (active && c < chunks) {
             half8_t v = xr[c];
             if constexpr (DELTA == 1) {
                 v = v + combine_chunk<4>(cy, cinv, cw, t, c, H, k_top, fp16_mode, k_top);
@@ -54,14 +56,14 @@ __global__ __launch_bounds__(NORM_THREADS) void add_rmsnorm_kernel(const half_t*
         }
     }
     ss = wave_sum(ss);
-    if ((tid & 63) == 0) part[tid >> 6] = ss;
+    if (active && (tid & 63) == 0) part[tid >> 6] = ss;
     __syncthreads();
     const float tot = part[0] + part[1] + part[2] + part[3];
     const float rs = rsqrtf(tot / (float)H + eps);
 #pragma unroll
     for (int u = 0; u < MAXC; u++) {
         const int c = tid + u * NORM_THREADS;
-        if (c < chunks) {
+        if (active && c < chunks) {
             const half8_t wv = reinterpret_cast<const half8_t*>(weight)[c];
             half8_t o;
 #pragma unroll
@@ -70,9 +72,41 @@ __global__ __launch_bounds__(NORM_THREADS) void add_rmsnorm_kernel(const half_t*
                 o[j] = (half_t)((float)wv[j] * n);
             }
             reinterpret_cast<half8_t*>(y + (int64_t)t * H)[c] = o;
+            if (y_copy) reinterpret_cast<half8_t*>(y_copy)[c] = o;
             if (resid_out) reinterpret_cast<half8_t*>(resid_out + (int64_t)t * H)[c] = r[u];
         }
     }
+}
+
+template <int DELTA>
+__global__ __launch_bounds__(NORM_THREADS) void add_rmsnorm_kernel(const half_t* __restrict__ x, const half_t* __restrict__ delta,
+                                                                   const half_t* __restrict__ weight, float eps, int H,
+                                                                   half_t* __restrict__ resid_out, half_t* __restrict__ y,
+                                                                   const half_t* __restrict__ cy, const int32_t* __restrict__ cinv,
+                                                                   const float* __restrict__ cw, int k_top, int fp16_mode) {
+    __shared__ float part[NORM_THREADS / 64];
+    add_rmsnorm_row<DELTA>(true, blockIdx.x, threadIdx.x, x, delta, weight, eps, H, resid_out, y, cy, cinv, cw, k_top, fp16_mode,
+                           part, nullptr);
+}
+
+// add + RMSNorm of a token's row, then the router on the normalised row (logits, top-k, softmax) by the same workgroup:
+// the norm in front of the MoE block and the router that reads its output, one launch.  The norm is the first
+// NORM_THREADS threads' work, exactly as add_rmsnorm_kernel does it; the router is router_topk_kernel's own code on the
+// row kept in LDS (the fp16 values that also go to y): same bits as the two launches.
+constexpr int NORM_ROUTER_THREADS = 512;
+__global__ __launch_bounds__(NORM_ROUTER_THREADS) void add_rmsnorm_router_kernel(
+    const half_t* __restrict__ x, const half_t* __restrict__ delta, const half_t* __restrict__ weight, float eps, int H,
+    half_t* __restrict__ resid_out, half_t* __restrict__ y, const half_t* __restrict__ wr, const half_t* __restrict__ br, int E,
+    int k, int32_t* __restrict__ ids, float* __restrict__ w) {
+    extern __shared__ __attribute__((aligned(16))) half_t yrow[];   // [H]
+    __shared__ float part[NORM_THREADS / 64];
+    __shared__ float logit[ROUTER_MAX_E];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    add_rmsnorm_row<0>(tid < NORM_THREADS, t, tid, x, delta, weight, eps, H, resid_out, y, nullptr, nullptr, nullptr, 0, 0, part, yrow);
+    __syncthreads();
+    router_logits_wg<NORM_ROUTER_THREADS / 64>(yrow, wr, br, H, E, logit, nullptr);
+    __syncthreads();
+    if (tid < 64) topk_softmax_wave(logit, E, k, ids + (int64_t)t * k, w + (int64_t)t * k);
 }
 
 // Rotate q and k (first half / second half pairing, every product and sum rounded to fp16), write q to q_out and
@@ -143,6 +177,28 @@ extern "C" int m355_add_rmsnorm(const void* x_f16, const void* delta_f16, const 
         (const half_t*)x_f16, (const half_t*)delta_f16, (const half_t*)weight_f16, eps, H, (half_t*)resid_out_f16, (half_t*)y_f16,
         nullptr, nullptr, nullptr, 0, 0);
     M355_LAUNCH_CHECK("add_rmsnorm_kernel");
+    return 0;
+}
+
+extern "C" int m355_add_rmsnorm_router(const void* x_f16, const void* delta_f16, const void* weight_f16, float eps, int T, int H,
+                                       void* resid_out_f16, void* y_f16, const void* wr_f16, const void* br_f16, int E, int k,
+                                       int32_t* ids, float* w, m355_stream_t stream) {
+    if (T == 0) return 0;
+    if (!x_f16 || !weight_f16 || !y_f16 || !wr_f16 || !ids || !w) return fail(-1, "m355_add_rmsnorm_router: null pointer");
+    if (T < 0 || H <= 0 || (H % 8) || H > 8 * NORM_THREADS * 4 || E <= 0 || E > ROUTER_MAX_E || k <= 0 || k > 32 || k > E)
+        return fail(-2, "m355_add_rmsnorm_router: unsupported shape T=%d H=%d E=%d k=%d (need H %% 8 == 0, H <= %d, E <= %d, k <= min(32, E))",
+                    T, H, E, k, 8 * NORM_THREADS * 4, ROUTER_MAX_E);
+    if (!aligned(x_f16, 16) || !aligned(weight_f16, 16) || !aligned(y_f16, 16) || !aligned(wr_f16, 16) ||
+        (delta_f16 && !aligned(delta_f16, 16)) || (resid_out_f16 && !aligned(resid_out_f16, 16)))
+        return fail(-3, "m355_add_rmsnorm_router: buffers must be 16-byte aligned");
+    if (T >= 1024) {   // many tokens: the router's 16-tokens-per-workgroup form takes over, as its own launch
+        if (int rc = m355_add_rmsnorm(x_f16, delta_f16, weight_f16, eps, T, H, resid_out_f16, y_f16, stream)) return rc;
+        return m355_router_topk(y_f16, wr_f16, br_f16, T, H, E, k, ids, w, nullptr, stream);
+    }
+    add_rmsnorm_router_kernel<<<dim3(T), dim3(NORM_ROUTER_THREADS), (size_t)H * 2, (hipStream_t)stream>>>(
+        (const half_t*)x_f16, (const half_t*)delta_f16, (const half_t*)weight_f16, eps, H, (half_t*)resid_out_f16, (half_t*)y_f16,
+        (const half_t*)wr_f16, (const half_t*)br_f16, E, k, ids, w);
+    M355_LAUNCH_CHECK("add_rmsnorm_router_kernel");
     return 0;
 }
 

@@ -26,7 +26,7 @@ EXPORTS = (
     "m355_version", "m355_last_error", "m355_nf4_dequant", "m355_repack_nf4", "m355_router_topk",
     "m355_topk_softmax", "m355_moe_nf4_forward", "m355_moe_workspace_bytes", "m355_paged_attn_decode",
     "m355_paged_attn_workspace_bytes", "m355_ep_row_bytes", "m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce",
-    "m355_add_rmsnorm", "m355_rope_kv_write", "m355_linear_f16", "m355_paged_attn_decode_ex",
+    "m355_add_rmsnorm", "m355_add_rmsnorm_router", "m355_rope_kv_write", "m355_linear_f16", "m355_paged_attn_decode_ex",
     "m355_repack_nf4_ex", "m355_moe_nf4_forward_ex", "m355_moe_nf4_forward_q8", "m355_repack_absmax_u8",
     "m355_moe_nf4_forward_routed", "m355_attn_prefill", "m355_moe_combine_add_rmsnorm", "m355_init",
     "m355_moe_nf4_forward_static", "m355_router_topk_ep_pack", "m355_moe_nf4_forward_ep_rows", "m355_ep_reduce_add_rmsnorm",
@@ -101,6 +101,8 @@ def load() -> ctypes.CDLL:
     L.m355_linear_f16.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp, vp]
     L.m355_linear_f16.restype = i32
     L.m355_add_rmsnorm.argtypes = [vp, vp, vp, ctypes.c_float, i32, i32, vp, vp, vp]
+    L.m355_add_rmsnorm_router.argtypes = [vp, vp, vp, ctypes.c_float, i32, i32, vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    L.m355_add_rmsnorm_router.restype = i32
     L.m355_moe_combine_add_rmsnorm.argtypes = [vp, sz, i32, i32, i32, i32, vp, i32, vp, vp, ctypes.c_float, i32, vp, vp, vp]
     L.m355_moe_combine_add_rmsnorm.restype = i32
     L.m355_rope_kv_write.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
@@ -507,6 +509,29 @@ def add_rmsnorm(x: torch.Tensor, delta: Optional[torch.Tensor], weight: torch.Te
                                    None if resid_out is None else _dev(resid_out, torch.float16, "resid_out"),
                                    _dev(out, torch.float16, "out"), _stream()), "m355_add_rmsnorm")
     return out
+
+
+def add_rmsnorm_router(x: torch.Tensor, delta: Optional[torch.Tensor], weight: torch.Tensor, eps: float, wr: torch.Tensor,
+                       br: Optional[torch.Tensor], k: int, resid_out: Optional[torch.Tensor] = None,
+                       out: Optional[torch.Tensor] = None, ids: Optional[torch.Tensor] = None, w: Optional[torch.Tensor] = None):
+    """add_rmsnorm and router_topk on its output in one launch.  Returns (out, ids, w).  m355_add_rmsnorm_router."""
+    T, H = x.shape
+    E = wr.shape[0]
+    if out is None:
+        out = torch.empty_like(x)
+    if ids is None:
+        ids = torch.empty((T, k), dtype=torch.int32, device=x.device)
+    if w is None:
+        w = torch.empty((T, k), dtype=torch.float32, device=x.device)
+    if wr.shape[1] != H or ids.shape != (T, k) or w.shape != (T, k):
+        raise ValueError("add_rmsnorm_router: shapes do not match")
+    _check(load().m355_add_rmsnorm_router(_dev(x, torch.float16, "x"), None if delta is None else _dev(delta, torch.float16, "delta"),
+                                          _dev(weight, torch.float16, "weight"), float(eps), T, H,
+                                          None if resid_out is None else _dev(resid_out, torch.float16, "resid_out"),
+                                          _dev(out, torch.float16, "out"), _dev(wr, torch.float16, "wr"),
+                                          None if br is None else _dev(br, torch.float16, "br"), E, k, _dev(ids, torch.int32, "ids"),
+                                          _dev(w, torch.float32, "w"), _stream()), "m355_add_rmsnorm_router")
+    return out, ids, w
 
 
 def moe_combine_add_rmsnorm(moe_workspace: torch.Tensor, w: torch.Tensor, *, FF: int, E_local: int, flags: int,

@@ -281,6 +281,16 @@ M355_API int m355_linear_f16(const void* x_f16, int T, const void* w_f16, const 
                              const void* resid_f16, void* out_f16, m355_stream_t stream);
 M355_API int m355_add_rmsnorm(const void* x_f16, const void* delta_f16, const void* weight_f16, float eps, int T, int H,
                               void* resid_out_f16, void* y_f16, m355_stream_t stream);
+/*
+ * m355_add_rmsnorm followed by m355_router_topk on its output y, in one launch (below 1024 tokens): the norm in front of
+ * the MoE block (GptOssDecoderLayer.forward, transformers models/gpt_oss/modeling_gpt_oss.py:372-374)
+ * and the router that reads it (GptOssTopKRouter.forward, :126-130; the reference casts it to fp16,
+ * patches/monkey_patch_router_fp16.py:1-19).  wr [E][H] fp16, br [E] fp16 or null; ids [T][k], w [T][k] as
+ * m355_router_topk writes them.  Same bits as the two calls.
+ */
+M355_API int m355_add_rmsnorm_router(const void* x_f16, const void* delta_f16, const void* weight_f16, float eps, int T, int H,
+                                     void* resid_out_f16, void* y_f16, const void* wr_f16, const void* br_f16, int E, int k,
+                                     int32_t* ids, float* w, m355_stream_t stream);
 /* m355_add_rmsnorm with the MoE combine step in front: the delta is formed here, exactly as the combine forms it, from
  * what a forward of the same T, k, H, FF, E_local called with M355_FLAG_SKIP_COMBINE left in `moe_workspace` (w: that
  * forward's routing weights, flags: its M355_FLAG_FP16_COMBINE), so a decoder stack spends one launch less per layer:

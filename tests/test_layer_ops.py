@@ -492,3 +492,26 @@ def test_gpu_prompt_through_decoder_layer_vs_transformers(name):
     torch.cuda.synchronize()
     dec = (resid_d.float() + moe_d.float()).cpu().numpy()[0]
     assert np.abs(dec - got[-1]).max() <= 2e-3 * np.abs(got[-1]).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,H,E,k,bias,delta", [(32, 2880, 32, 4, True, False), (1, 2880, 32, 4, False, True), (9, 256, 8, 3, True, True),
+                                                (300, 512, 128, 4, True, False), (1100, 256, 32, 4, True, True)])
+def test_add_rmsnorm_router_equals_the_two_launches(T, H, E, k, bias, delta, ref, m355, cuda):
+    """The norm in front of the MoE block and the router on its output in one launch: the bits of m355_add_rmsnorm then
+    m355_router_topk (from 1024 tokens the call is those two launches)."""
+    sd = ref.stream_seed(9500, T, H, E)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    x = dev(ref.normal_f16(ref.stream_seed(sd, 1), (T, H)))
+    d = dev(ref.normal_f16(ref.stream_seed(sd, 2), (T, H), 0.5)) if delta else None
+    nw = dev(ref.normal_f16(ref.stream_seed(sd, 3), (H,)))
+    wr = dev(ref.normal_f16(ref.stream_seed(sd, 4), (E, H), 0.05))
+    br = dev(ref.normal_f16(ref.stream_seed(sd, 5), (E,), 0.3)) if bias else None
+    r0 = torch.empty_like(x)
+    y0 = m355.add_rmsnorm(x, d, nw, 1e-5, resid_out=r0)
+    ids0, w0 = m355.router_topk(y0, wr, br, k)
+    r1 = torch.empty_like(x)
+    y1, ids1, w1 = m355.add_rmsnorm_router(x, d, nw, 1e-5, wr, br, k, resid_out=r1)
+    torch.cuda.synchronize()
+    assert torch.equal(y1.view(torch.int16), y0.view(torch.int16)) and torch.equal(r1.view(torch.int16), r0.view(torch.int16))
+    assert torch.equal(ids1, ids0) and torch.equal(w1.view(torch.int32), w0.view(torch.int32))
