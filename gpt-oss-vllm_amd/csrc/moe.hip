@@ -379,11 +379,9 @@ __device__ __forceinline__ void gemm_epilogue(float4_t accA, float4_t accB, half
 // One output element of an item: row 16p + `row` of the first tile (sumA) and the same row of the partner tile (sumB) for
 // token row `orow`: h = act(gate, up) (MODE 0) or the two y values (MODE 1), expert e.  Same arithmetic, element by
 // element, as gemm_epilogue.
-// `through` (MODE 1): the two stores go through to memory (device-scope stores), for readers on other compute dies of the
-// same launch.
 template <int MODE>
 __device__ __forceinline__ void gemm_epilogue1(float sumA, float sumB, half_t* __restrict__ outp, int64_t orow, int R, int NP,
-                                               int p, int row, int e, const StageParams& sp, bool through = false) {
+                                               int p, int row, int e, const StageParams& sp) {
     if (sp.bias) {
         sumA += (float)sp.bias[(int64_t)e * R + 16 * p + row];
         sumB += (float)sp.bias[(int64_t)e * R + 16 * (p + NP) + row];
@@ -402,13 +400,26 @@ __device__ __forceinline__ void gemm_epilogue1(float sumA, float sumB, half_t* _
             hv = (half_t)((float)sg * up);
         }
         outp[orow * (R / 2) + 16 * p + row] = hv;
-    } else if (through) {
-        store_device_scope(outp + orow * R + 16 * p + row, (half_t)sumA);
-        store_device_scope(outp + orow * R + 16 * (p + NP) + row, (half_t)sumB);
     } else {
         outp[orow * R + 16 * p + row] = (half_t)sumA;
         outp[orow * R + 16 * (p + NP) + row] = (half_t)sumB;
     }
+}
+
+// Down stage: rows `col` and `col + 1` (col even) of y for token row `orow` as one 4-byte store.  Same arithmetic,
+// element by element, as gemm_epilogue.  `through`: the store goes through to memory (a device-scope store), for readers
+// on other compute dies of the same launch.
+__device__ __forceinline__ void gemm_epilogue_y2(float sum0, float sum1, half_t* __restrict__ outp, int64_t orow, int R,
+                                                 int col, int e, const StageParams& sp, bool through) {
+    if (sp.bias) {
+        const half2_t b = *reinterpret_cast<const half2_t*>(sp.bias + (int64_t)e * R + col);
+        sum0 += (float)b[0];
+        sum1 += (float)b[1];
+    }
+    const half2_t v = {(half_t)sum0, (half_t)sum1};
+    half_t* dst = outp + orow * R + col;
+    if (through) store_device_scope(dst, v);
+    else *reinterpret_cast<half2_t*>(dst) = v;
 }
 
 // What a gate_up launch needs to bucket the (token, k) pairs by expert itself (INLINE), instead of reading the lists
@@ -892,14 +903,24 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
         if (tab_slot >= 0 && (THREADS == 256 || tid < 256)) ltab[tab_slot * 256 + (tid & 255)] = tab_new;   \
         lds_barrier();                                                                                      \
         M355_STAMP()                                                                                        \
-        {                                                                                                   \
+        if constexpr (MODE == 0) {                                                                          \
             const int s_ = q >> 2, r = q & 3;                                                               \
             float sumA = 0.f, sumB = 0.f;                                                                   \
             _Pragma("unroll") for (int qq = 0; qq < KP; qq++) {                                             \
                 sumA += rbuf[((qq * NT + s_) * 8 + r) * 64 + lane];                                         \
                 sumB += rbuf[((qq * NT + s_) * 8 + 4 + r) * 64 + lane];                                     \
             }                                                                                               \
-            if (live && n + 16 * s_ < mt) gemm_epilogue1<MODE>(sumA, sumB, outp, row0 + n + 16 * s_, R, NP, p, 4 * g + r, e, sp, MODE == 1 && cio.out != nullptr); \
+            if (live && n + 16 * s_ < mt) gemm_epilogue1<MODE>(sumA, sumB, outp, row0 + n + 16 * s_, R, NP, p, 4 * g + r, e, sp); \
+        } else {                                                                                            \
+            /* y needs no partner row: wave q takes rows 2 (q >> 1 & 1), + 1 of tile q & 1 -> one 4-byte store */ \
+            const int s_ = q >> 2, tile = q & 1, r = q & 2;                                                 \
+            float sum0 = 0.f, sum1 = 0.f;                                                                   \
+            _Pragma("unroll") for (int qq = 0; qq < KP; qq++) {                                             \
+                sum0 += rbuf[((qq * NT + s_) * 8 + 4 * tile + r) * 64 + lane];                              \
+                sum1 += rbuf[((qq * NT + s_) * 8 + 4 * tile + r + 1) * 64 + lane];                          \
+            }                                                                                               \
+            if (live && n + 16 * s_ < mt)                                                                   \
+                gemm_epilogue_y2(sum0, sum1, outp, row0 + n + 16 * s_, R, 16 * (p + tile * NP) + 4 * g + r, e, sp, cio.out != nullptr); \
         }                                                                                                   \
         pos0 = pos1;                                                                                        \
         pos1 = pos2;                                                                                        \
@@ -933,30 +954,60 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
 #endif
     if constexpr (MODE == 1) {
         if (cio.out) {
-            // The combine of this launch's own output.  The y values were stored through to memory (device-scope
-            // stores); every wave waits for its stores to be acknowledged, the workgroup meets, then one thread per
-            // finished item counts it on its column group (device-scope atomic).  Whoever brings a counter to the number
-            // of token tiles knows that all y values of those columns are in memory, and this workgroup combines them
-            // for every token, reading y with device-scope loads.  Nobody waits for another workgroup, and no cache is
-            // written back or invalidated as a whole.
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            int32_t* fin = reinterpret_cast<int32_t*>(red);   // [0]: count, [1..]: column groups this workgroup completed
+            // The combine of this launch's own output.  The y values were stored through to memory (4-byte device-scope
+            // stores).  Every wave waits until its own stores have been acknowledged (the explicit vmcnt(0): a
+            // workgroup-scope fence emits no such wait), the workgroup meets, and only then wave 0 counts the
+            // workgroup's finished items on their column groups (device-scope atomics that return the old value).
+            // Whoever brings a counter to the number of token tiles knows that every y value of those columns is in
+            // memory.  That workgroup then makes one device-scope acquire (its CU's L1 is invalidated; the wait behind
+            // it holds the barrier until the invalidate has completed) and combines the columns for every token,
+            // reading y with device-scope loads.  Nobody waits for another workgroup, and no L2 is written back.
+            constexpr int JOBS = PAIRS * 4;   // columns of pair p: [16p, 16p + 16) and [16(p + NP), ..): two 8-column chunks each
+            // A decode batch gives a thread at most one (token, chunk) job per finished column group and a token at most
+            // four pairs: their positions and routing weights (left by earlier launches) are requested up front, so that
+            // a workgroup that turns out to finish a column group is one trip to memory away from its y rows.
+            const bool few = k_top <= 4 && cio.T * JOBS <= THREADS;
+            const int my_t = tid / JOBS, my_wi = tid % JOBS;
+            int pos4[4] = {-1, -1, -1, -1};
+            float wf4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (few && my_t < cio.T) combine_fetch_pairs<4>(cio.inv, cio.w, my_t, 0, k_top, cio.w_stride, pos4, wf4);
+            // [0]: count, [1..]: column groups this workgroup completed (in the absmax table slots, which no wave reads
+            // after the last item's barrier; the reduction buffers may still be in use by a wave's epilogue)
+            int32_t* fin = reinterpret_cast<int32_t*>(ltab);
             if (tid == 0) fin[0] = 0;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             const int n_tt = (int)((uint32_t)total / (uint32_t)NPG);
-            for (int i = it0 + tid; i < it1; i += THREADS) {
-                const int pg_i = i % NPG;
-                const int before = __hip_atomic_fetch_add(cio.pg_done + pg_i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (before == n_tt - 1) fin[1 + atomicAdd(&fin[0], 1)] = pg_i;
+            if (wave == 0) {
+                for (int i = it0 + lane; i < it1; i += 64) {
+                    const int pg_i = i % NPG;
+                    const int before = __hip_atomic_fetch_add(cio.pg_done + pg_i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (before == n_tt - 1) fin[1 + atomicAdd(&fin[0], 1)] = pg_i;
+                }
             }
             __syncthreads();
             const int n_fin = fin[0];
-            if (n_fin > 0) {
-                // columns of pair p: [16p, 16p + 16) and [16(p + NP), ..): two 8-column chunks each
-                constexpr int JOBS = PAIRS * 4;
+            if (n_fin > 0) {   // (uniform over the workgroup)
+                if (wave == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
                 for (int j = 0; j < n_fin; j++) {
                     const int pg_c = fin[1 + j];
+                    if (few) {
+                        const int p = pg_c * PAIRS + my_wi / 4;
+                        if (my_t < cio.T && p < NP) {
+                            const int c = (my_wi & 2) ? 2 * (p + NP) + (my_wi & 1) : 2 * p + (my_wi & 1);
+                            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            combine_accumulate<4, true>(outp, pos4, wf4, c, R, cio.fp16_mode, acc);
+                            half8_t o;
+#pragma unroll
+                            for (int jj = 0; jj < 8; jj++) o[jj] = (half_t)acc[jj];
+                            reinterpret_cast<half8_t*>(cio.out + (int64_t)my_t * R)[c] = o;
+                        }
+                        continue;
+                    }
                     for (int job = tid; job < cio.T * JOBS; job += THREADS) {
                         const int t = job / JOBS, wi = job % JOBS;
                         const int p = pg_c * PAIRS + wi / 4;
@@ -1049,7 +1100,10 @@ int moe_device_init(int dev) {
     return tile_gemm_device_setup_once(dev);
 }
 
-constexpr int FOLD_COMBINE_MAX_PAIRS = 32;   // (token, k) pairs up to which the down launch also combines
+#ifndef M355_FOLD_MAX_PAIRS
+#define M355_FOLD_MAX_PAIRS 32
+#endif
+constexpr int FOLD_COMBINE_MAX_PAIRS = M355_FOLD_MAX_PAIRS;   // (token, k) pairs up to which the down launch also combines
 
 // mean (token, k) pairs per local expert from which the tile kernel takes over
 constexpr int TILE_MIN_MEAN_PAIRS = 80;   // measured crossover against the 32-token streaming form on gpt-oss-20b shapes (32 experts: 640 tokens)
@@ -1247,7 +1301,7 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
     // the counters the down launch counts on) and the batch is small: the y values then travel through memory as
     // device-scope 2-byte stores, which costs more than the saved launch from a few dozen (token, k) pairs on (measured:
     // 2.7 us per layer gained at 4 pairs, 6 us lost at 128).  M355_FLAG_FOLD_COMBINE folds at any size.
-    const bool fold_combine = !tiled && (P <= FOLD_COMBINE_MAX_PAIRS || (flags & M355_FLAG_FOLD_COMBINE)) && H / 64 <= MOE_KPARTS * MOE_CHUNK && FF / 64 <= MOE_KPARTS * MOE_CHUNK && H / 32 <= 2 * SYNC_PG_COUNTERS &&
+    const bool fold_combine = !tiled && (P <= FOLD_COMBINE_MAX_PAIRS || (flags & M355_FLAG_FOLD_COMBINE)) && H / 64 <= MOE_KPARTS * MOE_CHUNK && FF / 64 <= MOE_KPARTS * MOE_CHUNK && H / 32 <= SYNC_PG_COUNTERS &&
                               !(flags & (M355_FLAG_SKIP_GATE_UP | M355_FLAG_SKIP_DOWN | M355_FLAG_SKIP_COMBINE | M355_FLAG_SEPARATE_COMBINE));
     const CombineIO cio_gu = {nullptr, nullptr, nullptr, 0, 0, 0, fold_combine ? ws.pg_done : nullptr};
     const CombineIO cio_dn = {fold_combine ? (half_t*)out_f16 : nullptr, ws.inv, w, rows.w_stride, T,

@@ -25,6 +25,7 @@ struct MoeWorkspace {
 };
 
 constexpr int SYNC_PG_COUNTERS = 128;   // >= groups of output columns of the down stage (H <= 3072: at most 96)
+static_assert(SYNC_PG_COUNTERS >= 96, "one counter per 32 output columns of the down stage (H <= 3072, single-pair items)");
 
 __host__ inline MoeWorkspace carve_workspace(void* base, int T, int k, int H, int FF, int E_local) {
     const size_t P = (size_t)T * k;
@@ -61,8 +62,8 @@ struct StageParams {
 // Device-scope accesses: the store is performed at memory and the load is served from there, whichever compute die's L2
 // the address may sit in -- what workgroups of one launch need to hand data to each other across dies without writing
 // back or invalidating whole caches.
-__device__ __forceinline__ void store_device_scope(half_t* p, half_t v) {
-    __hip_atomic_store(reinterpret_cast<unsigned short*>(p), __builtin_bit_cast(unsigned short, v), __ATOMIC_RELAXED,
+__device__ __forceinline__ void store_device_scope(half_t* p, half2_t v) {   // p 4-byte aligned
+    __hip_atomic_store(reinterpret_cast<unsigned int*>(p), __builtin_bit_cast(unsigned int, v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ half8_t load_half8_device_scope(const half_t* p) {
@@ -92,6 +93,46 @@ struct CombineIO {
 // batch costs two memory round trips instead of two per pair.  Shared by the combine kernel and by the kernel that fuses
 // the combine with the residual add and RMSNorm that follow it, so both give the same bits.
 // THROUGH: y is read with device-scope loads (it was written by other workgroups of the same launch).
+// The positions and routing weights of KB pairs of token t, from pair k0 on (-1 / 0 past the token's last pair).
+template <int KB>
+__device__ __forceinline__ void combine_fetch_pairs(const int32_t* __restrict__ inv, const float* __restrict__ w, int t, int k0,
+                                                    int k_top, int w_stride, int (&pos)[KB], float (&wf)[KB]) {
+#pragma unroll
+    for (int i = 0; i < KB; i++) {
+        const bool in = k0 + i < k_top;
+        pos[i] = in ? inv[t * k_top + k0 + i] : -1;
+        wf[i] = in ? w[(int64_t)t * w_stride + k0 + i] : 0.f;
+    }
+}
+
+// acc += the weighted y rows of those KB pairs, columns 8c .. 8c + 7, in k order.
+template <int KB, bool THROUGH>
+__device__ __forceinline__ void combine_accumulate(const half_t* __restrict__ y, const int (&pos)[KB], const float (&wf)[KB],
+                                                   int c, int H, int fp16_mode, float (&acc)[8]) {
+    half8_t yv[KB];
+#pragma unroll
+    for (int i = 0; i < KB; i++)
+        if (pos[i] >= 0) {
+            if constexpr (THROUGH) yv[i] = load_half8_device_scope(y + (int64_t)pos[i] * H + 8 * c);
+            else yv[i] = reinterpret_cast<const half8_t*>(y + (int64_t)pos[i] * H)[c];
+        }
+#pragma unroll
+    for (int i = 0; i < KB; i++) {
+        if (pos[i] < 0) continue;
+        if (fp16_mode) {
+            const float w16 = (float)(half_t)wf[i];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const float prod = (float)(half_t)(w16 * (float)yv[i][j]);
+                acc[j] = (float)(half_t)(acc[j] + prod);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] += wf[i] * (float)yv[i][j];
+        }
+    }
+}
+
 template <int KB, bool THROUGH = false>
 __device__ __forceinline__ half8_t combine_chunk(const half_t* __restrict__ y, const int32_t* __restrict__ inv,
                                                  const float* __restrict__ w, int t, int c, int H, int k_top, int fp16_mode,
@@ -102,34 +143,8 @@ __device__ __forceinline__ half8_t combine_chunk(const half_t* __restrict__ y, c
     for (int k0 = 0; k0 < k_top; k0 += KB) {
         int pos[KB];
         float wf[KB];
-        half8_t yv[KB];
-#pragma unroll
-        for (int i = 0; i < KB; i++) {
-            const bool in = k0 + i < k_top;
-            pos[i] = in ? inv[t * k_top + k0 + i] : -1;
-            wf[i] = in ? w[(int64_t)t * w_stride + k0 + i] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < KB; i++)
-            if (pos[i] >= 0) {
-                if constexpr (THROUGH) yv[i] = load_half8_device_scope(y + (int64_t)pos[i] * H + 8 * c);
-                else yv[i] = reinterpret_cast<const half8_t*>(y + (int64_t)pos[i] * H)[c];
-            }
-#pragma unroll
-        for (int i = 0; i < KB; i++) {
-            if (pos[i] < 0) continue;
-            if (fp16_mode) {
-                const float w16 = (float)(half_t)wf[i];
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float prod = (float)(half_t)(w16 * (float)yv[i][j]);
-                    acc[j] = (float)(half_t)(acc[j] + prod);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; j++) acc[j] += wf[i] * (float)yv[i][j];
-            }
-        }
+        combine_fetch_pairs<KB>(inv, w, t, k0, k_top, w_stride, pos, wf);
+        combine_accumulate<KB, THROUGH>(y, pos, wf, c, H, fp16_mode, acc);
     }
     half8_t o;
 #pragma unroll
