@@ -240,11 +240,15 @@ def median(v):
 
 
 def roofline_gate_up(stepper, reps=5):
-    """Average duration of moe_gemm_kernel<gate_up> launches (HIP events on the launch stream, layers cycled
-    so the weights come from HBM) against the algorithmic bytes of the experts each launch streams."""
+    """Average duration of the streaming kernel's gate_up launches (HIP events on the launch stream, layers cycled so the
+    weights come from HBM) against the algorithmic bytes of the experts each launch streams.  `gate_up` is the launch as
+    the step runs it: the (token, k) pairs are bucketed inside it, and for up to 8 tokens it computes the router too;
+    `gate_up_given_routing` is the same launch handed finished routing lists (nothing in front of its first weight
+    load), `down` the down launch alone (in the step, small batches also combine inside it)."""
     lib = stepper.lib
     F = lib.FLAG_FP16_COMBINE
-    only_gate_up = F | lib.FLAG_SKIP_ROUTE | lib.FLAG_SKIP_DOWN | lib.FLAG_SKIP_COMBINE
+    gate_up_as_run = F | lib.FLAG_SKIP_DOWN | lib.FLAG_SKIP_COMBINE
+    only_gate_up = gate_up_as_run | lib.FLAG_SKIP_ROUTE
     only_down = F | lib.FLAG_SKIP_ROUTE | lib.FLAG_SKIP_GATE_UP | lib.FLAG_SKIP_COMBINE
     if stepper.world != 1:
         return None
@@ -257,10 +261,23 @@ def roofline_gate_up(stepper, reps=5):
         lay["_args"] = dict(E_local=ep.epr, e_first=0, H=H, FF=FF, workspace=ep.workspace, out=lay["out"])
         lib.moe_nf4_forward(lay["x"], lay["ids"], lay["w"], *ep.weights, flags=F | lib.FLAG_SKIP_COMBINE, **lay["_args"])
     torch.cuda.synchronize()
-    for name, flg, per_expert in (("gate_up", only_gate_up, GATE_UP_BYTES), ("down", only_down, DOWN_BYTES)):
+    router_inside = stepper.batch <= 8     # the step then calls the entry point that computes the router in the gate_up launch
+
+    def as_run(lay):
+        if router_inside:
+            lib.moe_nf4_forward_routed(lay["x"], lay["wr"], None, TOPK, *lay["ep"].weights, ids=lay["ids"], w=lay["w"],
+                                       flags=gate_up_as_run, **lay["_args"])
+        else:
+            lib.moe_nf4_forward(lay["x"], lay["ids"], lay["w"], *lay["ep"].weights, flags=gate_up_as_run, **lay["_args"])
+
+    def given(flg):
+        return lambda lay: lib.moe_nf4_forward(lay["x"], lay["ids"], lay["w"], *lay["ep"].weights, flags=flg, **lay["_args"])
+
+    for name, one, per_expert in (("gate_up", as_run, GATE_UP_BYTES), ("gate_up_given_routing", given(only_gate_up), GATE_UP_BYTES),
+                                  ("down", given(only_down), DOWN_BYTES)):
         def launches():
             for lay in stepper.L:
-                lib.moe_nf4_forward(lay["x"], lay["ids"], lay["w"], *lay["ep"].weights, flags=flg, **lay["_args"])
+                one(lay)
         # one graph of the 24 back-to-back launches of this kernel, so host launch cost stays out of the events
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -732,7 +749,23 @@ def main():
     ap.add_argument("--no-dequant-leg", action="store_true")
     ap.add_argument("--no-rank-of-8", action="store_true",
                     help="skip the leg that times the kernels one rank of an 8-way expert-parallel job launches per layer")
+    ap.add_argument("--legs", default="all",
+                    help="comma-separated legs to run beside the headline measurement (bs1, roofline, prefill, cpu_baseline, "
+                         "dequant, full, rank8, or none): profiling runs take one leg per trace so that a kernel row is one workload")
     a = ap.parse_args()
+    if a.legs != "all":
+        legs = set(a.legs.split(",")) - {"none", ""}
+        unknown = legs - {"bs1", "roofline", "prefill", "cpu_baseline", "dequant", "full", "rank8"}
+        if unknown:
+            raise SystemExit(f"--legs: unknown leg(s) {sorted(unknown)}")
+        a.no_bs1 |= "bs1" not in legs
+        a.no_roofline |= "roofline" not in legs
+        a.no_cpu_baseline |= "cpu_baseline" not in legs
+        a.no_dequant_leg |= "dequant" not in legs
+        a.no_full_layer |= "full" not in legs
+        a.no_rank_of_8 |= "rank8" not in legs
+        if "prefill" not in legs:
+            a.prefill_tokens = 0
     global E, LAYERS
     if a.shape == "120b":
         E, LAYERS = 128, 36
@@ -827,9 +860,12 @@ def main():
         if rank == 0 and world == 1 and not a.no_roofline:
             bs1.graph = None
             r1, act1 = roofline_gate_up(bs1)
-            out["roofline_gate_up"] = {"achieved": r1["gate_up"]["gbs"], "frac": r1["gate_up"]["gbs"] / HBM_PEAK_GBS,
-                                       "avg_us": r1["gate_up"]["avg_us"], "down_gbs": r1["down"]["gbs"],
-                                       "down_avg_us": r1["down"]["avg_us"]}
+            out["roofline_gate_up"] = {"kernel": "moe_gemm_stream_kernel<gate_up, route = inline + router>: the launch as the step runs it",
+                                       "achieved": r1["gate_up"]["gbs"], "frac": r1["gate_up"]["gbs"] / HBM_PEAK_GBS,
+                                       "avg_us": r1["gate_up"]["avg_us"],
+                                       "given_routing": {"avg_us": r1["gate_up_given_routing"]["avg_us"],
+                                                         "frac": r1["gate_up_given_routing"]["gbs"] / HBM_PEAK_GBS},
+                                       "down_gbs": r1["down"]["gbs"], "down_avg_us": r1["down"]["avg_us"]}
         return out
 
     def roofline_leg():
@@ -837,11 +873,13 @@ def main():
         traffic, traffic_src, stale = profiled_traffic()
         tflops = a.batch_per_gpu * TOPK * GATE_UP_FLOPS_PER_PAIR / (r["gate_up"]["avg_us"] * 1e-6) / 1e12
         return {
-            "bound": "hbm", "kernel": "moe_gemm_stream_kernel<gate_up> (NF4 dequant fused into the grouped GEMM)",
+            "bound": "hbm", "kernel": "moe_gemm_stream_kernel<gate_up, route = inline> (NF4 dequant fused into the grouped GEMM; "
+                                      "the launch as the step runs it, pairs bucketed inside)",
             "achieved": r["gate_up"]["gbs"], "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": r["gate_up"]["gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "traffic_stale": stale,
             "avg_us": r["gate_up"]["avg_us"], "algorithmic_bytes_per_launch": r["gate_up"]["bytes"],
+            "given_routing": {"avg_us": r["gate_up_given_routing"]["avg_us"], "frac": r["gate_up_given_routing"]["gbs"] / HBM_PEAK_GBS},
             "mean_active_experts": sum(active) / len(active),
             "down_kernel": {"achieved": r["down"]["gbs"], "avg_us": r["down"]["avg_us"],
                             "frac": r["down"]["gbs"] / HBM_PEAK_GBS},

@@ -58,16 +58,18 @@ ZERO_CODE_BYTE = 0x77   # two NF4 codes 7 = 0.0 (patches/streaming_unsloth_bnb.p
 def iter_layer_tensors(checkpoint_paths: List[str], layer_idx: int, num_experts: int, missing: str = "raise",
                        dims: Optional[Tuple[int, int]] = None) -> Iterator[Tuple[str, torch.Tensor]]:
     """(checkpoint name, tensor) pairs of every expert tensor of one layer, in expert order.  An expert matrix no shard
-    holds raises KeyError (missing="raise") or, with missing="zeros" and dims=(H, FF), is replaced by an all-zero matrix
-    (every code the NF4 zero, no absmax), which is what the reference substitutes for a missing gate_up
-    (patches/streaming_unsloth_bnb.py:261-264: such an expert contributes nothing)."""
+    holds raises KeyError (missing="raise").  With missing="zeros" and dims=(H, FF) a missing gate_up is replaced by an
+    all-zero matrix (every code the NF4 zero, no absmax), which is what the reference substitutes for it
+    (patches/streaming_unsloth_bnb.py:261-264); a missing down still raises: the reference attaches nothing for it
+    (:285-288) and has no forward that could say what such an expert computes.  Without biases an expert with a zero
+    gate_up contributes nothing (h = silu(0) * 0 = 0); with a down bias b2 it still contributes w * b2."""
     if missing not in ("raise", "zeros"):
         raise ValueError(f"missing={missing!r}: expected 'raise' or 'zeros'")
     for e in range(num_experts):
         for proj in ("gate_up", "down"):
             t = read_expert(checkpoint_paths, layer_idx, e, proj)
             if t is None:
-                if missing == "raise" or dims is None:
+                if missing == "raise" or dims is None or proj != "gate_up":
                     raise KeyError(f"{expert_weight_key(layer_idx, e, proj)} is in none of the shards")
                 H, FF = dims
                 n = 2 * FF * H if proj == "gate_up" else H * FF

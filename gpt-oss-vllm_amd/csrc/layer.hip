@@ -191,7 +191,7 @@ extern "C" int m355_add_rmsnorm_router(const void* x_f16, const void* delta_f16,
     if (!aligned(x_f16, 16) || !aligned(weight_f16, 16) || !aligned(y_f16, 16) || !aligned(wr_f16, 16) ||
         (delta_f16 && !aligned(delta_f16, 16)) || (resid_out_f16 && !aligned(resid_out_f16, 16)))
         return fail(-3, "m355_add_rmsnorm_router: buffers must be 16-byte aligned");
-    if (T >= 1024) {   // many tokens: the router's 16-tokens-per-workgroup form takes over, as its own launch
+    if (router_uses_tile_form(T, E, H)) {   // many tokens: the router's 16-tokens-per-workgroup form takes over, as its own launch
         if (int rc = m355_add_rmsnorm(x_f16, delta_f16, weight_f16, eps, T, H, resid_out_f16, y_f16, stream)) return rc;
         return m355_router_topk(y_f16, wr_f16, br_f16, T, H, E, k, ids, w, nullptr, stream);
     }

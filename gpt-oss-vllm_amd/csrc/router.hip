@@ -67,8 +67,6 @@ __global__ __launch_bounds__(ROUTER_THREADS) void router_topk_kernel(const half_
 // operand is 16 token rows (lane (r, g) loads x[token r][32 s + 8 g ..] straight from global memory), the B operand
 // 16 router rows per expert tile; the 4 waves take the 32-column steps s = wave, wave + 4, .. and their partial tiles
 // are summed through LDS in wave order; then each wave selects for 4 of the tokens.
-constexpr int ROUTER_TILE_MAX_E = 128;
-constexpr int ROUTER_TILE_MIN_T = 1024;   // below, one workgroup per token is faster (few workgroups of 16 tokens are latency-bound)
 template <int NJ>   // expert tiles of 16 (E <= 16 NJ)
 __global__ __launch_bounds__(256) void router_topk_tile_kernel(const half_t* __restrict__ x, const half_t* __restrict__ wr,
                                                                const half_t* __restrict__ br, int T, int H, int E, int k,
@@ -152,7 +150,7 @@ extern "C" int m355_router_topk(const void* x_f16, const void* wr_f16, const voi
                     T, H, E, k, ROUTER_MAX_E);
     if (!aligned(x_f16, 16) || !aligned(wr_f16, 16)) return fail(-3, "m355_router_topk: x and wr must be 16-byte aligned");
     if (T == 0) return 0;
-    if (T >= ROUTER_TILE_MIN_T && E <= ROUTER_TILE_MAX_E && (H % 32) == 0) {
+    if (router_uses_tile_form(T, E, H)) {
         const dim3 grid((T + 15) / 16), block(256);
         const size_t lds = 4 * 16 * E * sizeof(float);
         hipStream_t st = (hipStream_t)stream;
@@ -185,7 +183,7 @@ extern "C" int m355_router_topk_ep_pack(const void* x_f16, const void* wr_f16, c
                     n_ranks, experts_per_rank);
     if (!aligned(x_f16, 16) || !aligned(wr_f16, 16) || !aligned(send, 16))
         return fail(-3, "m355_router_topk_ep_pack: x, wr and send must be 16-byte aligned");
-    if (T >= ROUTER_TILE_MIN_T) {   // the 16-tokens-per-workgroup router does not pack: two launches
+    if (router_uses_tile_form(T, E, H)) {   // the 16-tokens-per-workgroup router does not pack: two launches
         if (int rc = m355_router_topk(x_f16, wr_f16, br_f16, T, H, E, k, ids, w, nullptr, stream)) return rc;
         return m355_ep_pack(x_f16, ids, w, T, k, H, n_ranks, experts_per_rank, send, stream);
     }

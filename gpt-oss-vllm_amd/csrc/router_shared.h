@@ -7,6 +7,16 @@ namespace m355 {
 
 constexpr int ROUTER_MAX_E = 1024;
 
+// Which of the two router kernels m355_router_topk runs: from ROUTER_TILE_MIN_T tokens on, 16 tokens per workgroup on the
+// matrix cores; below (few 16-token workgroups are latency-bound), or for shapes that form does not take, one workgroup
+// per token.  The two accumulate in different orders, so every caller that promises the bits of m355_router_topk (the
+// fused norm + router launch, the router + pack launch) decides with this same function.
+constexpr int ROUTER_TILE_MAX_E = 128;
+constexpr int ROUTER_TILE_MIN_T = 1024;
+__host__ __device__ inline bool router_uses_tile_form(int T, int E, int H) {
+    return T >= ROUTER_TILE_MIN_T && E <= ROUTER_TILE_MAX_E && (H % 32) == 0;
+}
+
 // Wave-wide arg-max over (v, idx): larger v wins, on equal v the smaller idx wins.
 __device__ __forceinline__ void wave_argmax(float& v, int& idx) {
 #pragma unroll

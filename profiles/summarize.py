@@ -4,17 +4,26 @@ import collections
 import csv
 import glob
 import json
+import os
 import shutil
 import sys
 
 tag = sys.argv[1]
 src = f"gpurun_out/prof_{tag}"
-stats = glob.glob(f"{src}/trace/*/*kernel_stats.csv")[0]
-trace = glob.glob(f"{src}/trace/*/*kernel_trace.csv")[0]
-shutil.copy(stats, f"profiles/{tag}_bench_kernel_stats.csv")
-shutil.copy(f"{src}/bench_line.json", f"profiles/{tag}_bench_line.json")
-for extra in glob.glob(f"{src}/trace_bs1/*/*kernel_stats.csv"):
-    shutil.copy(extra, f"profiles/{tag}_bench_bs1_kernel_stats.csv")
+# (label, directory, what the run was)
+LEGS = [
+    ("hot path bs=32", "hot32", "`bench.py --steps 10 --warmup 3 --legs roofline`: the headline step (attention, router, gate_up, down, combine) "
+                                "and the roofline leg's launches of the same gate_up / down kernels on the same inputs"),
+    ("hot path bs=1", "hot1", "the same with `--batch-per-gpu 1` (gate_up computes the router, the down launch combines)"),
+    ("prefill 8192 tokens", "prefill", "`--legs prefill`: prompt attention, tiled router, routing, tile kernel, combine (+ a few bs=32 headline steps)"),
+    ("whole decoder stack", "full", "`--legs full`: 24 whole decoder layers at bs=32 and bs=1 (+ a few bs=32 headline steps)"),
+    ("dequant / rank of 8", "side", "`--legs dequant,rank8`: the standalone dequantiser and the kernels of one rank of an 8-way shard (+ a few bs=32 headline steps)"),
+]
+for _, d, _ in LEGS:
+    for f in glob.glob(f"{src}/trace_{d}/*/*kernel_stats.csv"):
+        shutil.copy(f, f"profiles/{tag}_{d}_kernel_stats.csv")
+    if os.path.exists(f"{src}/bench_line_{d}.json"):
+        shutil.copy(f"{src}/bench_line_{d}.json", f"profiles/{tag}_bench_line_{d}.json")
 
 import re
 
@@ -40,16 +49,15 @@ def short_name(mangled):
 
 
 groups = collections.defaultdict(list)
-traces = [("bs=32", trace)] + [("bs=1", t) for t in glob.glob(f"{src}/trace_bs1/*/*kernel_trace.csv")]
-for leg, tr_file in traces:
-  for r in csv.DictReader(open(tr_file)):
-      n = r["Kernel_Name"]
-      if "m355" not in n:
-          continue
-      short = short_name(n)
-      key = (leg, short, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Workgroup_Size_X"]), int(r["LDS_Block_Size"]),
-             int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]))
-      groups[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+for leg, d, _ in LEGS:
+    for tr_file in glob.glob(f"{src}/trace_{d}/*/*kernel_trace.csv"):
+        for r in csv.DictReader(open(tr_file)):
+            n = r["Kernel_Name"]
+            if "m355" not in n:
+                continue
+            key = (leg, short_name(n), int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"]), int(r["Workgroup_Size_X"]), int(r["LDS_Block_Size"]),
+                   int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]))
+            groups[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 
 tile_pmc = collections.defaultdict(list)
 mfma_busy = {}
@@ -64,16 +72,31 @@ for f in glob.glob(f"{src}/pmc_rd/*/*counter_collection.csv") + glob.glob(f"{src
         if "moe_gemm" in r["Kernel_Name"]:
             pmc[("gate_up" if "ILi0E" in r["Kernel_Name"] else "down", r["Counter_Name"])].append(float(r["Counter_Value"]))
 
-bench = json.load(open(f"{src}/bench_line.json"))
+lines = {d: json.load(open(f"{src}/bench_line_{d}.json")) for _, d, _ in LEGS if os.path.exists(f"{src}/bench_line_{d}.json")}
 with open(f"profiles/{tag}_summary.md", "w") as out:
-    out.write(f"# {tag}: rocprofv3 --kernel-trace --stats of `python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-bs1 [--batch-per-gpu 1]`\n\n")
-    out.write("Two runs: the default workload (bs=32 per GPU) and `--batch-per-gpu 1`; both with `--no-bs1` so a row is one configuration. "
-              "Each run ends with the 8192-token prefill leg: its launches are attn_prefill, router_topk_tile, moe_route, "
-              "moe_tile_gemm and the moe_combine rows with 8192 workgroups.\n\n")
-    out.write("| leg | kernel | workgroups | threads | launches | avg us | min us | max us |\n|---|---|---|---|---|---|---|---|\n")
-    for k, v in sorted(groups.items()):
-        out.write(f"| {k[0]} | {k[1]} | {k[2]} | {k[3]} | {len(v)} | {sum(v) / len(v) / 1e3:.2f} | {min(v) / 1e3:.2f} | {max(v) / 1e3:.2f} |\n")
-    out.write("\n## bench.py line of the same run\n\n```\n" + json.dumps(bench, indent=1) + "\n```\n")
+    out.write(f"# {tag}: rocprofv3 --kernel-trace --stats of bench.py, one run per leg\n\n")
+    for leg, d, what in LEGS:
+        rows = sorted((k, v) for k, v in groups.items() if k[0] == leg)
+        if not rows:
+            continue
+        out.write(f"## {leg}\n\n{what}\n\n")
+        out.write("| kernel | workgroups | threads | launches | avg us | min us | max us |\n|---|---|---|---|---|---|---|\n")
+        for k, v in rows:
+            out.write(f"| {k[1]} | {k[2]} | {k[3]} | {len(v)} | {sum(v) / len(v) / 1e3:.2f} | {min(v) / 1e3:.2f} | {max(v) / 1e3:.2f} |\n")
+        line = lines.get(d)
+        if line and d in ("hot32", "hot1") and isinstance(line.get("roofline"), dict) and "avg_us" in line["roofline"]:
+            r = line["roofline"]
+            gu = [v for k, v in rows if k[1].startswith("moe_gemm_stream<gate_up") and "listed" not in k[1]]
+            if gu:
+                v = max(gu, key=len)
+                avg = sum(v) / len(v) / 1e3
+                out.write(f"\nbench.py's own figure for the gate_up launch as the step runs it (HIP events around 24 back-to-back launches in one "
+                          f"graph, so it includes the gaps between launches): {r['avg_us']:.2f} us, frac {r['frac']:.3f}; the trace row above: "
+                          f"{avg:.2f} us over {len(v)} launches ({(r['avg_us'] / avg - 1) * 100:+.1f} %).\n")
+        out.write("\n")
+    for _, d, _ in LEGS:
+        if d in lines:
+            out.write(f"## bench.py line of the `{d}` run\n\n```\n" + json.dumps(lines[d], indent=1) + "\n```\n\n")
     if pmc:
         out.write("\n## HBM traffic of the MoE GEMM kernels (separate --pmc passes over scratch/prof_moe.py, bs=32, per launch)\n\n")
         out.write("| kernel | counter | launches | mean |\n|---|---|---|---|\n")

@@ -141,20 +141,26 @@ def test_per_block_absmax_rejects_unrepresentable_blocks():
 
 
 def test_checkpoint_missing_expert_policy(tmp_path):
-    """A matrix no shard holds: KeyError by default; with missing="zeros" an all-zero matrix, as the reference
-    substitutes zeros for a missing gate_up (patches/streaming_unsloth_bnb.py:261-264)."""
+    """A matrix no shard holds: KeyError by default; with missing="zeros" an all-zero matrix for a missing gate_up, as the
+    reference substitutes (patches/streaming_unsloth_bnb.py:261-264); a missing down raises either way (the reference
+    attaches nothing for it, :285-288)."""
     from safetensors.torch import save_file
     from gpt_oss_vllm_amd import checkpoint
     H, FF = 64, 64
-    k0 = checkpoint.expert_weight_key(0, 0, "gate_up")
+    kg0, kd0, kd1 = (checkpoint.expert_weight_key(0, e, p) for e, p in ((0, "gate_up"), (0, "down"), (1, "down")))
     shard = str(tmp_path / "s.safetensors")
-    save_file({k0: torch.zeros((2 * FF * H // 2, 1), dtype=torch.uint8), k0 + ".absmax": torch.ones(2 * FF * H // 64)}, shard)
+    save_file({kg0: torch.zeros((2 * FF * H // 2, 1), dtype=torch.uint8), kg0 + ".absmax": torch.ones(2 * FF * H // 64),
+               kd1: torch.zeros((H * FF // 2, 1), dtype=torch.uint8), kd1 + ".absmax": torch.ones(H * FF // 64)}, shard)
     with pytest.raises(KeyError):
         list(checkpoint.iter_layer_tensors([shard], 0, 1))
-    got = dict(checkpoint.iter_layer_tensors([shard], 0, 2, missing="zeros", dims=(H, FF)))
-    kd = checkpoint.expert_weight_key(0, 1, "down")
-    assert got[kd].numel() == H * FF // 2 and (got[kd] == 0x77).all() and kd + ".absmax" not in got
-    assert got[checkpoint.expert_weight_key(0, 1, "gate_up")].numel() == FF * H
+    with pytest.raises(KeyError, match="down_projs.0"):       # expert 0 has no down matrix: zeros do not stand in for it
+        list(checkpoint.iter_layer_tensors([shard], 0, 2, missing="zeros", dims=(H, FF)))
+    save_file({kd0: torch.zeros((H * FF // 2, 1), dtype=torch.uint8), kd0 + ".absmax": torch.ones(H * FF // 64)},
+              str(tmp_path / "t.safetensors"))
+    got = dict(checkpoint.iter_layer_tensors([shard, str(tmp_path / "t.safetensors")], 0, 2, missing="zeros", dims=(H, FF)))
+    kg1 = checkpoint.expert_weight_key(0, 1, "gate_up")       # expert 1 has no gate_up matrix
+    assert got[kg1].numel() == FF * H and (got[kg1] == 0x77).all() and kg1 + ".absmax" not in got
+    assert got[kd1].numel() == H * FF // 2
     with pytest.raises(ValueError):
         list(checkpoint.iter_layer_tensors([shard], 0, 1, missing="skip"))
 

@@ -496,7 +496,11 @@ def test_gpu_prompt_through_decoder_layer_vs_transformers(name):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,H,E,k,bias,delta", [(32, 2880, 32, 4, True, False), (1, 2880, 32, 4, False, True), (9, 256, 8, 3, True, True),
-                                                (300, 512, 128, 4, True, False), (1100, 256, 32, 4, True, True)])
+                                                (300, 512, 128, 4, True, False), (1100, 256, 32, 4, True, True),
+                                                # either side of the token count at which m355_router_topk changes kernels, and a
+                                                # shape its 16-token form does not take (more than 128 experts)
+                                                (1023, 256, 32, 4, True, False), (1024, 256, 32, 4, False, True),
+                                                (1030, 256, 160, 4, True, False)])
 def test_add_rmsnorm_router_equals_the_two_launches(T, H, E, k, bias, delta, ref, m355, cuda):
     """The norm in front of the MoE block and the router on its output in one launch: the bits of m355_add_rmsnorm then
     m355_router_topk (from 1024 tokens the call is those two launches)."""

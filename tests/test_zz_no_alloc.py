@@ -30,7 +30,8 @@ def _layer(ref, m355, cuda, E, H, FF, seed):
 def test_static_workspace_entry_equals_workspace_entry(H, FF, E, k, sizes, ref, m355, cuda):
     lay, tl = _layer(ref, m355, cuda, E, H, FF, ref.stream_seed(H, FF, E, 606))
     L = m355.load()
-    m355.init(0)      # set-up: kernel attributes and the address of the library's device array (loads its code object)
+    # set-up on the device the tensors live on: kernel attributes and the address of the library's device array
+    m355.init(cuda.index if cuda.index is not None else torch.cuda.current_device())
     stream = torch.cuda.current_stream().cuda_stream
     for T in sizes:       # the second call is smaller: it must not read what the first left in the shared array
         x = _dev(ref.normal_f16(ref.stream_seed(606, T, 1), (T, H)), cuda)
@@ -53,6 +54,23 @@ def test_static_workspace_entry_equals_workspace_entry(H, FF, E, k, sizes, ref, 
             assert torch.cuda.mem_get_info()[0] >= free_before   # the call took no device memory
             assert torch.isfinite(got.float()).all()
             assert torch.equal(got, want)
+            # the stronger check: under stream capture a hipMalloc / hipFree is an error that invalidates the capture, so a
+            # call that is captured, instantiated and replayed with the right result has made none
+            got2 = torch.full((T, H), float("nan"), dtype=torch.float16, device=cuda)
+            side = torch.cuda.Stream(device=cuda)
+            side.wait_stream(torch.cuda.current_stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    rc = L.m355_moe_nf4_forward_static(
+                        x.data_ptr(), T, ids.data_ptr(), w.data_ptr(), k, tl[0].data_ptr(), tl[1].data_ptr(), tl[2].data_ptr(),
+                        tl[3].data_ptr(), E, 0, H, FF, act, m355.FLAG_FP16_COMBINE, b13.data_ptr() if bias else None,
+                        b2.data_ptr() if bias else None, ctypes.c_float(1.702), ctypes.c_float(7.0), got2.data_ptr(),
+                        side.cuda_stream)
+            assert rc == 0, L.m355_last_error()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(got2, want)
             if act == m355.ACT_SILU_CONCAT and H == 256:
                 ref_out = ref.moe_forward(x.cpu().numpy(), ids.cpu().numpy(), w.cpu().numpy(), **lay, E_local=E, H=H, FF=FF)
                 lim = 2e-3 * np.abs(ref_out.astype(np.float32)).max() + 1e-5
