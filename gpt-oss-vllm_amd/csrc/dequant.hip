@@ -5,44 +5,60 @@
 
 namespace m355 {
 
-// Each work item turns 4 packed bytes (8 weights) into 16 bytes of fp16, so a wave reads 256
-// contiguous bytes and writes 1 KiB contiguous per step.  The code book is looked up per byte in
-// LDS as a float2 (low-nibble code, high-nibble code); products are taken in fp32 and rounded to
-// nearest even, which reproduces the reference bit for bit.
-__global__ __launch_bounds__(256) void nf4_dequant_kernel(const uint32_t* __restrict__ q,
-                                                          const float* __restrict__ absmax, int64_t n_items,
-                                                          int blocksize, u32x4_t* __restrict__ out) {
-    __shared__ float2 lut[256];
+// A work item turns 4 packed bytes (8 weights) into 16 bytes of fp16.  A wave takes 256 consecutive items per step
+// (1 KiB in, 4 KiB out): lane l handles items l, l + 64, l + 128, l + 192 of them, so every load instruction reads 256
+// contiguous bytes and every store instruction writes 1 KiB contiguous.  The code book is looked up per byte in LDS as
+// a float2 (low-nibble code, high-nibble code) from a table with 256-byte rows and one replica per lane of a 32-lane
+// group (64 KiB, conflict-free ds_read_b64; the address of a lookup is one v_perm_b32: the byte dropped into bits 8..15
+// above the lane's replica offset, which needs the table at LDS address 0 -- it is the kernel's only LDS).  Products are
+// taken in fp32 and rounded to nearest even, which reproduces the reference bit for bit.  The block of an item is
+// item >> shift when blocksize / 8 is a power of two (the checkpoint's 64 and 128 are), else a 64-bit division.
+constexpr int DQ_THREADS = 1024;   // two workgroups per CU share the LDS: 32 waves per CU keep enough loads in flight
+__device__ const float nf4_code[16] = M355_NF4_TABLE;
+
+__global__ __launch_bounds__(DQ_THREADS) void nf4_dequant_kernel(const uint32_t* __restrict__ q,
+                                                                 const float* __restrict__ absmax, int64_t n_items,
+                                                                 int items_per_block, int shift, u32x4_t* __restrict__ out) {
+    typedef float __attribute__((ext_vector_type(2))) f2_t;
+    __shared__ __attribute__((aligned(16))) f2_t lut[256 * 32];
     {
-        const float tab[16] = M355_NF4_TABLE;
-        const int b = threadIdx.x;
-        lut[b] = make_float2(tab[b & 15], tab[b >> 4]);
+        // thread t writes replica t & 31 of byte values (t >> 5) + 32 i: a 32-lane group touches every bank pair once
+        const int r = threadIdx.x & 31, b0 = threadIdx.x >> 5;
+#pragma unroll
+        for (int i = 0; i < 256 * 32 / DQ_THREADS; i++) {
+            const int b = b0 + (DQ_THREADS / 32) * i;
+            lut[b * 32 + r] = f2_t{nf4_code[b & 15], nf4_code[b >> 4]};
+        }
     }
     __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    typedef const f2_t __attribute__((address_space(3))) lds_f2_t;
+    const int lane = threadIdx.x & 63;
+    const uint32_t lbase = (uint32_t)(size_t)(lds_f2_t*)lut + (lane & 31) * 8;
+    const int64_t wave0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (DQ_THREADS / 64) + (threadIdx.x >> 6)));
+    const int64_t n_waves = (int64_t)gridDim.x * (DQ_THREADS / 64);
     constexpr int U = 4;
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; base < n_items; base += stride * U) {
+    for (int64_t base = wave0 * (64 * U); base < n_items; base += n_waves * (64 * U)) {
         uint32_t pk[U];
         float am[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int64_t it = base + u * stride;
+            const int64_t it = base + u * 64 + lane;
             const bool ok = it < n_items;
             pk[u] = ok ? __builtin_nontemporal_load(q + it) : 0u;
-            am[u] = ok ? absmax[(it * 8) / blocksize] : 0.f;
+            am[u] = ok ? absmax[shift >= 0 ? (it >> shift) : (it / items_per_block)] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int64_t it = base + u * stride;
-            if (it >= n_items) continue;
-            u32x4_t o;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float2 c = lut[(pk[u] >> (8 * j)) & 0xffu];
-                const half2_t h = {(half_t)(c.x * am[u]), (half_t)(c.y * am[u])};
-                o[j] = __builtin_bit_cast(uint32_t, h);
-            }
-            __builtin_nontemporal_store(o, out + it);
+            const int64_t it = base + u * 64 + lane;
+            uint32_t a0 = __builtin_amdgcn_perm(pk[u], lbase, 0x03020400u), a1 = __builtin_amdgcn_perm(pk[u], lbase, 0x03020500u);
+            uint32_t a2 = __builtin_amdgcn_perm(pk[u], lbase, 0x03020600u), a3 = __builtin_amdgcn_perm(pk[u], lbase, 0x03020700u);
+            const f2_t c0 = *reinterpret_cast<lds_f2_t*>(a0), c1 = *reinterpret_cast<lds_f2_t*>(a1);
+            const f2_t c2 = *reinterpret_cast<lds_f2_t*>(a2), c3 = *reinterpret_cast<lds_f2_t*>(a3);
+            const half2_t h0 = {(half_t)(c0.x * am[u]), (half_t)(c0.y * am[u])}, h1 = {(half_t)(c1.x * am[u]), (half_t)(c1.y * am[u])};
+            const half2_t h2 = {(half_t)(c2.x * am[u]), (half_t)(c2.y * am[u])}, h3 = {(half_t)(c3.x * am[u]), (half_t)(c3.y * am[u])};
+            const u32x4_t o = {__builtin_bit_cast(uint32_t, h0), __builtin_bit_cast(uint32_t, h1), __builtin_bit_cast(uint32_t, h2),
+                               __builtin_bit_cast(uint32_t, h3)};
+            if (it < n_items) __builtin_nontemporal_store(o, out + it);
         }
     }
 }
@@ -119,10 +135,18 @@ extern "C" int m355_nf4_dequant(const uint8_t* q, const float* absmax, int64_t n
                     (long long)n, blocksize);
     if (!aligned(q, 4) || !aligned(out_f16, 16)) return fail(-3, "m355_nf4_dequant: q must be 4-byte and out 16-byte aligned");
     const int64_t items = n / 8;
-    int64_t blocks = (items + 256 * 4 - 1) / (256 * 4);
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    nf4_dequant_kernel<<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream>>>(
-        reinterpret_cast<const uint32_t*>(q), absmax, items, blocksize, reinterpret_cast<u32x4_t*>(out_f16));
+    const int ipb = blocksize / 8;
+    int shift = -1;
+    if ((ipb & (ipb - 1)) == 0) { shift = 0; while ((1 << shift) < ipb) shift++; }
+    // persistent: up to two workgroups per CU (their code tables fill the LDS), each wave walking 1 KiB-in steps
+    int dev = 0, cus = 0;
+    if (int rc = hip_status(hipGetDevice(&dev), "hipGetDevice")) return rc;
+    if (int rc = hip_status(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute")) return rc;
+    if (cus <= 0) cus = 256;
+    int64_t blocks = (items + DQ_THREADS * 4 - 1) / (DQ_THREADS * 4);
+    if (blocks > 2 * cus) blocks = 2 * cus;
+    nf4_dequant_kernel<<<dim3((unsigned)blocks), dim3(DQ_THREADS), 0, (hipStream_t)stream>>>(
+        reinterpret_cast<const uint32_t*>(q), absmax, items, ipb, shift, reinterpret_cast<u32x4_t*>(out_f16));
     M355_LAUNCH_CHECK("m355_nf4_dequant");
     return 0;
 }

@@ -1,8 +1,8 @@
 #!/bin/bash
-# dq_ab.sh <name> ...: the standalone dequant leg of bench.py against scratch/exp/<name>.so on one box
+# dq_ab.sh v1 v2 ...: the standalone dequantiser's time for each variant library in scratch/exp
 for v in "$@"; do
-  echo "== $v"
-  M355_LIB_PATH=$PWD/scratch/exp/$v.so timeout -k 10 300 python bench.py --steps 3 --warmup 1 --windows 1 --no-cpu-baseline --no-bs1 --no-roofline --prefill-tokens 0 --no-full-layer --no-rank-of-8 2>&1 | tail -1 | python -c "
+  M355_LIB_PATH=$PWD/scratch/exp/$v.so timeout -k 10 200 python bench.py --legs dequant --steps 3 --windows 1 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read())['dequant']; print('dequant %.1f us  %.0f GB/s  frac %.3f' % (d['avg_us'], d['achieved'], d['frac']))" || exit 1
+d=json.loads(sys.stdin.read())['dequant']
+print('$v %.1f us frac %.3f' % (d['avg_us'], d['frac']))" || exit 1
 done
