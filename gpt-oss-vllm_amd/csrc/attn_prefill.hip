@@ -26,6 +26,7 @@ constexpr int AP_D = 64;
 constexpr int AP_G = 8;
 constexpr int AP_TILE_BYTES = AP_KVBLK * AP_D * 2;   // 8 KiB: one K (or V) tile
 constexpr int AP_LDS = 4 * AP_TILE_BYTES;            // K and V, two buffers each
+constexpr float AP_LAZY = 6.0f;                      // log2 units the running maximum may exceed the exponents' reference point
 
 typedef const half8_t __attribute__((address_space(3))) ap_lds_h8_t;
 typedef __attribute__((address_space(3))) short4_t ap_lds_s4_t;
@@ -140,21 +141,31 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
             for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, x[i]), x[i + 1]);
             mx = fmaxf(mx, x[15]);
             mx = cross_half_max(mx) * scale2;
-            const float m_new = fmaxf(m_run, mx);
+            // The reference point of the exponents follows the running maximum lazily: it moves only when the maximum has
+            // grown by more than AP_LAZY (log2 units) beyond it, so the probabilities are at most 2^AP_LAZY instead of 1
+            // (fp16 holds them; the denominator carries the same factor) and the accumulator is rescaled a few times per
+            // query instead of whenever any of the 32 queries sees a new maximum.
+            const float m_top = fmaxf(m_run, mx);
+            const bool move = m_top > m_run + AP_LAZY;          // (-inf + AP_LAZY = -inf: the first visible key moves it)
+            const float m_new = move ? m_top : m_run;
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;   // every key so far masked: all terms are 0
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            const float alpha = move ? __builtin_amdgcn_exp2f(m_run - m_use) : 1.0f;
             float rs = 0.f;
             half8_t pf[2];
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], scale2, -m_use));
-                rs += p;
-                pf[i >> 3][i & 7] = (half_t)p;
+            for (int i = 0; i < 16; i += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], scale2, -m_use));
+                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i + 1], scale2, -m_use));
+                const half2_t ph = {(half_t)p0, (half_t)p1};
+                pf[i >> 3][i & 7] = ph[0];
+                pf[i >> 3][(i & 7) + 1] = ph[1];
+                // the denominator sums the probabilities as the second product sees them (rounded to fp16), two per instruction
+                rs = __builtin_amdgcn_fdot2(ph, half2_t{(half_t)1.0f, (half_t)1.0f}, rs, false);
             }
             rs = cross_half_sum(rs);
             l_run = l_run * alpha + rs;
             m_run = m_new;
-            if (__any(alpha != 1.0f)) {   // (once the running maxima have settled nothing is rescaled)
+            if (__any(move)) {
 #pragma unroll
                 for (int i = 0; i < 16; i++) { o[0][i] *= alpha; o[1][i] *= alpha; }
             }
