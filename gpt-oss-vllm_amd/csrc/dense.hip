@@ -16,8 +16,11 @@ constexpr int DENSE_KPARTS = 8;
 
 __device__ __forceinline__ void dense_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// STEPS = 64-column blocks per wave and item (K <= 64 * 8 * STEPS); NT = token tiles (T <= 16 * NT).
-template <int STEPS, int NT>
+// STEPS = 64-column blocks per wave and item (K <= 64 * 8 * STEPS); NT = token tiles (T <= 16 * NT); ROWS = rows of W per
+// item, 16 or 8.  With 8 the lanes of rows 8..15 load rows 0..7 again (the same lines: no further HBM traffic) and their
+// results are dropped: half-size items for shapes whose 16-row tiles do not spread evenly over the CUs (5120 rows are 320
+// tiles for 256 CUs: two rounds for 1.25 rounds of work, against three half rounds with 8-row items).
+template <int STEPS, int NT, int ROWS = 16>
 __global__ __launch_bounds__(DENSE_THREADS) void dense_stream_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
                                                                      const half_t* __restrict__ bias,
                                                                      const half_t* __restrict__ resid, int T, int N, int K,
@@ -26,7 +29,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_stream_kernel(const half_
     const int tid = threadIdx.x, lane = tid & 63;
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, g = lane >> 4;
-    const int NB = K / 64, tiles = N / 16;
+    const int NB = K / 64, tiles = N / ROWS;
     const int it0 = (int)((int64_t)blockIdx.x * tiles / gridDim.x), it1 = (int)((int64_t)(blockIdx.x + 1) * tiles / gridDim.x);
     if (it0 >= it1) return;
     const int b0 = q * NB / DENSE_KPARTS, b1 = (q + 1) * NB / DENSE_KPARTS;   // this wave's blocks
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_stream_kernel(const half_
     // per-lane byte offsets into a 16-row tile of W: row (lane & 15), columns 64 * block + 16 * g (+ 8)
     uint32_t voff[STEPS];
 #pragma unroll
-    for (int s = 0; s < STEPS; s++) voff[s] = (uint32_t)n * (uint32_t)K * 2u + (uint32_t)(min(b0 + s, NB - 1) * 64 + 16 * g) * 2u;
+    for (int s = 0; s < STEPS; s++) voff[s] = (uint32_t)(n & (ROWS - 1)) * (uint32_t)K * 2u + (uint32_t)(min(b0 + s, NB - 1) * 64 + 16 * g) * 2u;
 
     // B fragments: token (16 * tile + n, clamped), the same columns; zero where the slot is outside this wave's part
     half8_t xb[NT][STEPS][2];
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_stream_kernel(const half_
         A[S][1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>((BASE) + voff[S] + 16));           \
     }
     {
-        const unsigned char* base = wb + (size_t)it0 * 16 * K * 2;
+        const unsigned char* base = wb + (size_t)it0 * ROWS * K * 2;
 #pragma unroll
         for (int s = 0; s < STEPS; s++) DENSE_LOAD(s, base)
     }
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_stream_kernel(const half_
 #define DENSE_ITEM(IT, LOAD)                                                                                      \
     {                                                                                                             \
         const int it = (IT);                                                                                      \
-        const unsigned char* next = wb + (size_t)(it + 1) * 16 * K * 2;                                           \
+        const unsigned char* next = wb + (size_t)(it + 1) * ROWS * K * 2;                                         \
         (void)next;                                                                                               \
         float4_t acc[NT];                                                                                         \
         _Pragma("unroll") for (int tt = 0; tt < NT; tt++) acc[tt] = float4_t{0.f, 0.f, 0.f, 0.f};                 \
@@ -95,8 +98,8 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_stream_kernel(const half_
                 _Pragma("unroll") for (int qq = 0; qq < DENSE_KPARTS - 1; qq++)                                   \
                     acc[tt] += *reinterpret_cast<const float4_t*>(red[buf][qq][tt][lane]);                        \
                 const int tok = 16 * tt + n;                                                                      \
-                if (tok < T) {                                                                                    \
-                    const int col = 16 * it + 4 * g; /* accumulator rows 4g..4g+3 of the tile = output columns */ \
+                if (tok < T && 4 * g < ROWS) {                                                                    \
+                    const int col = ROWS * it + 4 * g; /* accumulator rows 4g..4g+3 of the tile = output columns */ \
                     half4_t o;                                                                                    \
                     const half4_t bv = bias ? *reinterpret_cast<const half4_t*>(bias + col) : half4_t{0, 0, 0, 0}; \
                     _Pragma("unroll") for (int r = 0; r < 4; r++) o[r] = (half_t)(acc[tt][r] + (float)bv[r]);     \
@@ -114,12 +117,109 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_stream_kernel(const half_
 #undef DENSE_LOAD
 }
 
+// A handful of tokens (T <= 4: single-sequence decode).  The 16-row tiles of the kernel above are too coarse a unit
+// there: 5120 rows are 320 tiles for 256 CUs, two rounds for 1.25 rounds of work, and a CU cannot stream faster than its
+// own share of the HBM bandwidth.  Here the unit is half a row of W: a workgroup owns a contiguous run of rows (N / grid,
+// so every CU streams the same number of bytes), its 8 waves take (row, K-half) units round-robin -- a wave keeps one
+// K-half, so its slice of x stays in registers --, every lane multiplies 16-byte pieces with v_dot2_f32_f16, a wave-wide
+// sum finishes a unit, and the two halves of a row meet in LDS.  All of a wave's loads of a batch of rows are requested
+// before the first is used.  Same roundings as above: fp16(acc + bias), the residual added in fp16.
+constexpr int GEMV_MAX_T = 4;
+constexpr int GEMV_ROWS = 24;   // rows of a batch: 48 units, 6 per wave
+constexpr int GEMV_UNITS = GEMV_ROWS * 2 / DENSE_KPARTS;
+
+template <int TN, int J>   // tokens; 16-byte pieces per lane and K-half (K / 2 <= 512 J elements)
+__global__ __launch_bounds__(DENSE_THREADS) void dense_gemv_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
+                                                                   const half_t* __restrict__ bias,
+                                                                   const half_t* __restrict__ resid, int N, int K,
+                                                                   half_t* __restrict__ out) {
+    __shared__ float part[GEMV_ROWS][2][TN];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r0 = (int)((int64_t)blockIdx.x * N / gridDim.x), r1 = (int)((int64_t)(blockIdx.x + 1) * N / gridDim.x);
+    const int kh = wv & 1;                  // this wave's K-half
+    const int C = K / 16;                   // 16-byte pieces per half row
+    const half_t* xh = x + kh * (K / 2);
+    const half_t* wh = w + kh * (K / 2);
+    // the wave's slice of x: piece lane + 64 j of its K-half, every token
+    u32x4_t xr[TN][J];
+#pragma unroll
+    for (int t = 0; t < TN; t++)
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c = lane + 64 * j;
+            xr[t][j] = c < C ? reinterpret_cast<const u32x4_t*>(xh + (int64_t)t * K)[c] : u32x4_t{0u, 0u, 0u, 0u};
+        }
+    for (int rb = r0; rb < r1; rb += GEMV_ROWS) {
+        const int rows = min(GEMV_ROWS, r1 - rb);
+        u32x4_t a[GEMV_UNITS][J];
+#pragma unroll
+        for (int u = 0; u < GEMV_UNITS; u++) {
+            const int lr = (wv >> 1) + (DENSE_KPARTS / 2) * u;   // local row of the wave's u-th unit
+            if (lr < rows) {                                     // (uniform over the wave)
+                const half_t* row = wh + (int64_t)(rb + lr) * K;
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    const int c = min(lane + 64 * j, C - 1);     // (pieces past the half row meet a zero in xr)
+                    a[u][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(row) + c);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GEMV_UNITS; u++) {
+            const int lr = (wv >> 1) + (DENSE_KPARTS / 2) * u;
+            if (lr >= rows) break;
+            float acc[TN];
+#pragma unroll
+            for (int t = 0; t < TN; t++) {
+                acc[t] = 0.f;
+#pragma unroll
+                for (int j = 0; j < J; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        acc[t] = __builtin_amdgcn_fdot2(as_half2(a[u][j][i]), as_half2(xr[t][j][i]), acc[t], false);
+                acc[t] = wave_sum(acc[t]);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int t = 0; t < TN; t++) part[lr][kh][t] = acc[t];
+            }
+        }
+        __syncthreads();
+        if (tid < rows * TN) {
+            const int lr = tid / TN, t = tid - lr * TN;
+            const int col = rb + lr;
+            half_t o = (half_t)(part[lr][0][t] + part[lr][1][t] + (bias ? (float)bias[col] : 0.f));
+            if (resid) o = o + resid[(int64_t)t * N + col];
+            out[(int64_t)t * N + col] = o;
+        }
+        __syncthreads();
+    }
+}
+
+template <int TN>
+static int launch_gemv(const half_t* x, const half_t* w, const half_t* bias, const half_t* resid, int N, int K, half_t* out,
+                       int cus, hipStream_t st) {
+    const int grid = N < cus ? N : cus;
+    const int J = (K / 16 + 63) / 64;
+    switch (J) {
+    case 1: dense_gemv_kernel<TN, 1><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, resid, N, K, out); break;
+    case 2: dense_gemv_kernel<TN, 2><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, resid, N, K, out); break;
+    case 3: dense_gemv_kernel<TN, 3><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, resid, N, K, out); break;
+    default: dense_gemv_kernel<TN, 4><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, resid, N, K, out); break;
+    }
+    M355_LAUNCH_CHECK("dense_gemv_kernel");
+    return 0;
+}
+
 template <int STEPS, int NT>
 static int launch_dense(const half_t* x, const half_t* w, const half_t* bias, const half_t* resid, int T, int N, int K,
                         half_t* out, int cus, hipStream_t st) {
     const int tiles = N / 16;
+    // (8-row items -- ROWS = 8 -- even out shapes like 5120 rows = 320 tiles on 256 CUs, and measure slower: 16.3 against
+    // 14.7 us at 32 tokens, 11.8 against 10.4 at 5: an item's fixed cost outweighs the shorter last round)
     const int grid = tiles < cus ? tiles : cus;
-    dense_stream_kernel<STEPS, NT><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, resid, T, N, K, out);
+    dense_stream_kernel<STEPS, NT, 16><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, resid, T, N, K, out);
     M355_LAUNCH_CHECK("dense_stream_kernel");
     return 0;
 }
@@ -151,6 +251,14 @@ extern "C" int m355_linear_f16(const void* x_f16, int T, const void* w_f16, cons
     const half_t *x = (const half_t*)x_f16, *w = (const half_t*)w_f16, *b = (const half_t*)bias_f16, *r = (const half_t*)resid_f16;
     half_t* out = (half_t*)out_f16;
     if (T >= DENSE_TILE_MIN_T) return launch_dense_tile(x, w, b, r, T, N, K, out, cus, st);
+    if (T <= GEMV_MAX_T && K <= 64 * 64 * 4) {   // at most 4 pieces of 8 elements per lane and K-half
+        switch (T) {
+        case 1: return launch_gemv<1>(x, w, b, r, N, K, out, cus, st);
+        case 2: return launch_gemv<2>(x, w, b, r, N, K, out, cus, st);
+        case 3: return launch_gemv<3>(x, w, b, r, N, K, out, cus, st);
+        default: return launch_gemv<4>(x, w, b, r, N, K, out, cus, st);
+        }
+    }
     const bool small_k = K <= 64 * DENSE_KPARTS * 6;
     // 32 tokens per pass; more tokens re-stream W once per pass (decode batches above 32 are the exception here)
     for (int t0 = 0; t0 < T; t0 += 32) {

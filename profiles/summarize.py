@@ -83,16 +83,19 @@ with open(f"profiles/{tag}_summary.md", "w") as out:
         out.write("| kernel | workgroups | threads | launches | avg us | min us | max us |\n|---|---|---|---|---|---|---|\n")
         for k, v in rows:
             out.write(f"| {k[1]} | {k[2]} | {k[3]} | {len(v)} | {sum(v) / len(v) / 1e3:.2f} | {min(v) / 1e3:.2f} | {max(v) / 1e3:.2f} |\n")
-        line = lines.get(d)
-        if line and d in ("hot32", "hot1") and isinstance(line.get("roofline"), dict) and "avg_us" in line["roofline"]:
-            r = line["roofline"]
+        plain_file = f"{src}/bench_line_plain{d[3:]}.json" if d in ("hot32", "hot1") else None
+        if plain_file and os.path.exists(plain_file):
+            line = json.load(open(plain_file))
+            shutil.copy(plain_file, f"profiles/{tag}_bench_line_plain{d[3:]}.json")
+            r = line.get("roofline")
             gu = [v for k, v in rows if k[1].startswith("moe_gemm_stream<gate_up") and "listed" not in k[1]]
-            if gu:
+            if isinstance(r, dict) and "avg_us" in r and gu:
                 v = max(gu, key=len)
                 avg = sum(v) / len(v) / 1e3
-                out.write(f"\nbench.py's own figure for the gate_up launch as the step runs it (HIP events around 24 back-to-back launches in one "
-                          f"graph, so it includes the gaps between launches): {r['avg_us']:.2f} us, frac {r['frac']:.3f}; the trace row above: "
-                          f"{avg:.2f} us over {len(v)} launches ({(r['avg_us'] / avg - 1) * 100:+.1f} %).\n")
+                out.write(f"\nbench.py's own figure for the gate_up launch as the step runs it, from a run of the same command without the "
+                          f"profiler (HIP events around 24 back-to-back launches in one graph, so it includes the gaps between launches): "
+                          f"{r['avg_us']:.2f} us, frac {r['frac']:.3f}; the trace row above (kernel time alone): {avg:.2f} us over {len(v)} "
+                          f"launches ({(r['avg_us'] / avg - 1) * 100:+.1f} %).  ms_per_step of that run: {line['ms_per_step']:.3f}.\n")
         out.write("\n")
     for _, d, _ in LEGS:
         if d in lines:

@@ -12,6 +12,10 @@ trace_leg() {   # trace_leg <name> <bench.py arguments...>
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag/trace_$name -- python bench.py "$@" > gpurun_out/prof_${tag}_bench_$name.log 2>&1 || { tail -5 gpurun_out/prof_${tag}_bench_$name.log; exit 1; }
   grep '^{' gpurun_out/prof_${tag}_bench_$name.log > gpurun_out/prof_$tag/bench_line_$name.json
 }
+# the same two runs without the profiler first: under rocprofv3 every launch of a graph carries the tracer's own cost, so the
+# bench's HIP-event figures of the traced runs read high; the summary compares the trace rows with these plain runs
+timeout -k 10 300 python bench.py --legs roofline 2> gpurun_out/prof_${tag}_plain32.err | grep '^{' > gpurun_out/prof_$tag/bench_line_plain32.json || exit 1
+timeout -k 10 300 python bench.py --legs roofline --batch-per-gpu 1 2> gpurun_out/prof_${tag}_plain1.err | grep '^{' > gpurun_out/prof_$tag/bench_line_plain1.json || exit 1
 trace_leg hot32 --steps 10 --warmup 3 --legs roofline
 trace_leg hot1 --steps 10 --warmup 3 --legs roofline --batch-per-gpu 1
 trace_leg prefill --steps 2 --warmup 1 --windows 1 --legs prefill

@@ -113,6 +113,10 @@ def test_gpu_rope_kv_write():
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,N,K,bias,resid", [(1, 5120, 2880, True, False), (32, 2880, 4096, True, True),
                                               (40, 64, 256, True, True), (17, 48, 64, False, False), (5, 16, 3072, False, True),
+                                              # up to 4 tokens: the half-row kernel (rows not a multiple of the row batch,
+                                              # fewer rows than workgroups, K with a ragged last piece, the largest K)
+                                              (1, 2880, 4096, True, True), (2, 5120, 2880, False, True), (3, 48, 64, True, False),
+                                              (4, 2880, 4096, True, True), (4, 7184, 192, False, False), (1, 16, 4096, True, True),
                                               # from 128 tokens on: the tiled kernel (whole and ragged token tiles, row groups)
                                               (128, 5120, 2880, True, False), (300, 2880, 4096, True, True),
                                               (1000, 48, 64, False, True), (2049, 272, 128, True, True), (257, 512, 192, False, False)])
