@@ -300,6 +300,18 @@ def roofline_gate_up(stepper, reps=5):
         bytes_per_launch = sum(active) / len(active) * per_expert
         res[name] = dict(avg_us=avg_us, bytes=bytes_per_launch, gbs=bytes_per_launch / (avg_us * 1e-6) / 1e9)
         del g
+        # the launch alone: a pair of events around every launch (plain launches, so the GPU idles between them and the
+        # figure holds no gap to a neighbour: what a kernel trace reports as the kernel's duration)
+        pairs = []
+        for _ in range(3):
+            for lay in stepper.L:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                one(lay)
+                b.record()
+                pairs.append((a, b))
+        torch.cuda.synchronize()
+        res[name]["alone_us"] = median([a.elapsed_time(b) * 1e3 for a, b in pairs])
     return res, active
 
 
@@ -862,7 +874,7 @@ def main():
             r1, act1 = roofline_gate_up(bs1)
             out["roofline_gate_up"] = {"kernel": "moe_gemm_stream_kernel<gate_up, route = inline + router>: the launch as the step runs it",
                                        "achieved": r1["gate_up"]["gbs"], "frac": r1["gate_up"]["gbs"] / HBM_PEAK_GBS,
-                                       "avg_us": r1["gate_up"]["avg_us"],
+                                       "avg_us": r1["gate_up"]["avg_us"], "launch_alone_us": r1["gate_up"]["alone_us"],
                                        "given_routing": {"avg_us": r1["gate_up_given_routing"]["avg_us"],
                                                          "frac": r1["gate_up_given_routing"]["gbs"] / HBM_PEAK_GBS},
                                        "down_gbs": r1["down"]["gbs"], "down_avg_us": r1["down"]["avg_us"]}
@@ -879,6 +891,9 @@ def main():
             "unit": "GB/s", "frac": r["gate_up"]["gbs"] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "traffic_stale": stale,
             "avg_us": r["gate_up"]["avg_us"], "algorithmic_bytes_per_launch": r["gate_up"]["bytes"],
+            "avg_us_is": "24 launches back to back in one HIP graph, events around the graph: includes the gap between dependent launches",
+            "launch_alone": {"us": r["gate_up"]["alone_us"], "frac": r["gate_up"]["bytes"] / (r["gate_up"]["alone_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                             "what": "median over 72 plain launches of an event pair around each one: the kernel's own duration, as a kernel trace reports it"},
             "given_routing": {"avg_us": r["gate_up_given_routing"]["avg_us"], "frac": r["gate_up_given_routing"]["gbs"] / HBM_PEAK_GBS},
             "mean_active_experts": sum(active) / len(active),
             "down_kernel": {"achieved": r["down"]["gbs"], "avg_us": r["down"]["avg_us"],

@@ -74,6 +74,16 @@ __device__ __forceinline__ float dpp_get(float v) {   // lanes outside ROW_MASK 
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
 }
 // Wave-wide sum with DPP only (no LDS crossbar round trips); every lane returns the total.
+// Rotary embedding of one (first half, second half) pair of a head, as transformers' _apply_rotary_emb computes it on
+// fp16 tensors: every product and every sum is rounded to fp16 (a fused multiply-add would skip a rounding).
+__device__ __forceinline__ void rope_rotate(half_t a, half_t b, half_t c, half_t s, half_t& o1, half_t& o2) {
+#pragma clang fp contract(off)
+    const half_t ac = (half_t)((float)a * (float)c), bs = (half_t)((float)b * (float)s);
+    const half_t bc = (half_t)((float)b * (float)c), as = (half_t)((float)a * (float)s);
+    o1 = (half_t)((float)ac - (float)bs);
+    o2 = (half_t)((float)bc + (float)as);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_get<0xB1>(v);          // quad_perm [1,0,3,2]
     v += dpp_get<0x4E>(v);          // quad_perm [2,3,0,1]

@@ -197,6 +197,123 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_gemv_kernel(const half_t*
     }
 }
 
+// The q/k/v projection of up to 4 tokens with what follows it in a decoder layer -- rotary embedding of q and k, q to
+// its own buffer, k and v into the paged cache -- in the projection's launch.  The half-row kernel above, with the rows
+// taken as pairs (d, d + D/2) of a head (the two values a rotation mixes; v rows pair up the same way and pass through),
+// so the thread that adds a pair's K-halves has both values at hand.  Same sums, same roundings: the bits of
+// m355_linear_f16 followed by m355_rope_kv_write.
+struct RopeKvArgs {
+    const half_t *cos_t, *sin_t;
+    const int32_t* positions;
+    const int64_t* slots;
+    int Hq, Hkv, D, block_size, max_pos;
+    half_t *q_out, *kcache, *vcache;
+};
+
+template <int TN, int J>
+__global__ __launch_bounds__(DENSE_THREADS) void qkv_rope_gemv_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
+                                                                      const half_t* __restrict__ bias, int N, int K,
+                                                                      RopeKvArgs ra) {
+    __shared__ float part[GEMV_ROWS][2][TN];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half_d = ra.D / 2, n_pairs = N / 2;
+    const int p0 = (int)((int64_t)blockIdx.x * n_pairs / gridDim.x), p1 = (int)((int64_t)(blockIdx.x + 1) * n_pairs / gridDim.x);
+    const int kh = wv & 1;
+    const int C = K / 16;
+    const half_t* xh = x + kh * (K / 2);
+    const half_t* wh = w + kh * (K / 2);
+    // local row lr of a batch that starts at pair pb: pair pb + lr / 2, its first (even lr) or second (odd lr) row
+    auto row_of = [&](int pb, int lr) {
+        const int p = pb + (lr >> 1);
+        const int head = p / half_d, d = p - head * half_d;
+        return head * ra.D + d + (lr & 1) * half_d;
+    };
+    u32x4_t xr[TN][J];
+#pragma unroll
+    for (int t = 0; t < TN; t++)
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c = lane + 64 * j;
+            xr[t][j] = c < C ? reinterpret_cast<const u32x4_t*>(xh + (int64_t)t * K)[c] : u32x4_t{0u, 0u, 0u, 0u};
+        }
+    for (int pb = p0; pb < p1; pb += GEMV_ROWS / 2) {
+        const int pairs = min(GEMV_ROWS / 2, p1 - pb), rows = 2 * pairs;
+        u32x4_t a[GEMV_UNITS][J];
+#pragma unroll
+        for (int u = 0; u < GEMV_UNITS; u++) {
+            const int lr = (wv >> 1) + (DENSE_KPARTS / 2) * u;
+            if (lr < rows) {
+                const half_t* row = wh + (int64_t)row_of(pb, lr) * K;
+#pragma unroll
+                for (int j = 0; j < J; j++) {
+                    const int c = min(lane + 64 * j, C - 1);
+                    a[u][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(row) + c);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < GEMV_UNITS; u++) {
+            const int lr = (wv >> 1) + (DENSE_KPARTS / 2) * u;
+            if (lr >= rows) break;
+            float acc[TN];
+#pragma unroll
+            for (int t = 0; t < TN; t++) {
+                acc[t] = 0.f;
+#pragma unroll
+                for (int j = 0; j < J; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        acc[t] = __builtin_amdgcn_fdot2(as_half2(a[u][j][i]), as_half2(xr[t][j][i]), acc[t], false);
+                acc[t] = wave_sum(acc[t]);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int t = 0; t < TN; t++) part[lr][kh][t] = acc[t];
+            }
+        }
+        __syncthreads();
+        if (tid < pairs * TN) {
+            const int lp = tid / TN, t = tid - lp * TN;
+            const int ra_row = row_of(pb, 2 * lp), rb_row = ra_row + half_d;
+            const half_t va = (half_t)(part[2 * lp][0][t] + part[2 * lp][1][t] + (bias ? (float)bias[ra_row] : 0.f));
+            const half_t vb = (half_t)(part[2 * lp + 1][0][t] + part[2 * lp + 1][1][t] + (bias ? (float)bias[rb_row] : 0.f));
+            const int head = ra_row / ra.D, d = ra_row - head * ra.D;
+            const int64_t slot = ra.slots[t];
+            const int64_t cache_row = slot >= 0 ? ((slot / ra.block_size) * ra.block_size + slot % ra.block_size) * (int64_t)ra.Hkv * ra.D : -1;
+            if (head < ra.Hq + ra.Hkv) {
+                const int pos = min(max(ra.positions[t], 0), ra.max_pos - 1);
+                half_t o1, o2;
+                rope_rotate(va, vb, ra.cos_t[(int64_t)pos * half_d + d], ra.sin_t[(int64_t)pos * half_d + d], o1, o2);
+                half_t* dst = nullptr;
+                if (head < ra.Hq) dst = ra.q_out + ((int64_t)t * ra.Hq + head) * ra.D;
+                else if (cache_row >= 0) dst = ra.kcache + cache_row + (head - ra.Hq) * ra.D;
+                if (dst) { dst[d] = o1; dst[d + half_d] = o2; }
+            } else if (cache_row >= 0) {
+                half_t* dst = ra.vcache + cache_row + (head - ra.Hq - ra.Hkv) * ra.D;
+                dst[d] = va;
+                dst[d + half_d] = vb;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int TN>
+static int launch_qkv_rope(const half_t* x, const half_t* w, const half_t* bias, int N, int K, const RopeKvArgs& ra, int cus,
+                           hipStream_t st) {
+    const int grid = N / 2 < cus ? N / 2 : cus;
+    const int J = (K / 16 + 63) / 64;
+    switch (J) {
+    case 1: qkv_rope_gemv_kernel<TN, 1><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, N, K, ra); break;
+    case 2: qkv_rope_gemv_kernel<TN, 2><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, N, K, ra); break;
+    case 3: qkv_rope_gemv_kernel<TN, 3><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, N, K, ra); break;
+    default: qkv_rope_gemv_kernel<TN, 4><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, N, K, ra); break;
+    }
+    M355_LAUNCH_CHECK("qkv_rope_gemv_kernel");
+    return 0;
+}
+
 template <int TN>
 static int launch_gemv(const half_t* x, const half_t* w, const half_t* bias, const half_t* resid, int N, int K, half_t* out,
                        int cus, hipStream_t st) {
@@ -272,4 +389,41 @@ extern "C" int m355_linear_f16(const void* x_f16, int T, const void* w_f16, cons
         if (rc) return rc;
     }
     return 0;
+}
+
+extern "C" int m355_qkv_rope_kv_write(const void* x_f16, int T, const void* wqkv_f16, const void* bqkv_f16, int K,
+                                      const void* cos_f16, const void* sin_f16, const int32_t* positions, const int64_t* slots,
+                                      int Hq, int Hkv, int D, int block_size, int max_pos, void* qkv_scratch_f16,
+                                      void* q_out_f16, void* kcache_f16, void* vcache_f16, m355_stream_t stream) {
+    if (T == 0) return 0;
+    if (!x_f16 || !wqkv_f16 || !cos_f16 || !sin_f16 || !positions || !slots || !q_out_f16 || !kcache_f16 || !vcache_f16)
+        return fail(-1, "m355_qkv_rope_kv_write: null pointer");
+    if (T < 0 || Hq <= 0 || Hkv <= 0 || D <= 0 || (D % 16) || block_size <= 0 || max_pos <= 0 || K <= 0 || (K % 64))
+        return fail(-2, "m355_qkv_rope_kv_write: unsupported shape T=%d Hq=%d Hkv=%d D=%d K=%d block_size=%d (need D %% 16 == 0, K %% 64 == 0)",
+                    T, Hq, Hkv, D, K, block_size);
+    const int N = (Hq + 2 * Hkv) * D;
+    if (T <= GEMV_MAX_T && K <= 64 * 64) {
+        if (!aligned(x_f16, 16) || !aligned(wqkv_f16, 16) || (bqkv_f16 && !aligned(bqkv_f16, 2)) || !aligned(cos_f16, 2) ||
+            !aligned(sin_f16, 2) || !aligned(q_out_f16, 2) || !aligned(kcache_f16, 2) || !aligned(vcache_f16, 2))
+            return fail(-3, "m355_qkv_rope_kv_write: x and wqkv must be 16-byte aligned");
+        int dev = 0, cus = 0;
+        if (int rc = hip_status(hipGetDevice(&dev), "hipGetDevice")) return rc;
+        if (int rc = hip_status(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute")) return rc;
+        if (cus <= 0) cus = 256;
+        const RopeKvArgs ra = {(const half_t*)cos_f16, (const half_t*)sin_f16, positions, slots, Hq, Hkv, D, block_size, max_pos,
+                               (half_t*)q_out_f16, (half_t*)kcache_f16, (half_t*)vcache_f16};
+        const half_t *x = (const half_t*)x_f16, *w = (const half_t*)wqkv_f16, *b = (const half_t*)bqkv_f16;
+        hipStream_t st = (hipStream_t)stream;
+        switch (T) {
+        case 1: return launch_qkv_rope<1>(x, w, b, N, K, ra, cus, st);
+        case 2: return launch_qkv_rope<2>(x, w, b, N, K, ra, cus, st);
+        case 3: return launch_qkv_rope<3>(x, w, b, N, K, ra, cus, st);
+        default: return launch_qkv_rope<4>(x, w, b, N, K, ra, cus, st);
+        }
+    }
+    // more tokens: the two launches, through the caller's qkv buffer
+    if (!qkv_scratch_f16) return fail(-1, "m355_qkv_rope_kv_write: more than %d tokens need the qkv scratch buffer", GEMV_MAX_T);
+    if (int rc = m355_linear_f16(x_f16, T, wqkv_f16, bqkv_f16, N, K, nullptr, qkv_scratch_f16, stream)) return rc;
+    return m355_rope_kv_write(qkv_scratch_f16, cos_f16, sin_f16, positions, slots, T, Hq, Hkv, D, block_size, max_pos, q_out_f16,
+                              kcache_f16, vcache_f16, stream);
 }

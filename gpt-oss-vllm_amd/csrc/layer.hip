@@ -137,11 +137,10 @@ __global__ __launch_bounds__(ROPE_THREADS) void rope_kv_write_kernel(const half_
         half8_t o1, o2;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-#pragma clang fp contract(off)   /* a fused multiply-add would skip the rounding of the products */
-            const half_t ac = (half_t)((float)a[j] * (float)c[j]), bs = (half_t)((float)b[j] * (float)s[j]);
-            const half_t bc = (half_t)((float)b[j] * (float)c[j]), as = (half_t)((float)a[j] * (float)s[j]);
-            o1[j] = (half_t)((float)ac - (float)bs);
-            o2[j] = (half_t)((float)bc + (float)as);
+            half_t r1, r2;
+            rope_rotate(a[j], b[j], c[j], s[j], r1, r2);
+            o1[j] = r1;
+            o2[j] = r2;
         }
         half_t* dst;
         if (head < Hq) {

@@ -178,8 +178,9 @@ class GptOssDecodeLayer:
                                         weight=w["ln1"], eps=self.eps, resid_out=self.resid, out=self.h1)
         else:
             lib.add_rmsnorm(resid_in, delta, w["ln1"], self.eps, resid_out=self.resid, out=self.h1)
-        lib.linear_f16(self.h1, w["wqkv"], w.get("bqkv"), out=self.qkv)
-        lib.rope_kv_write(self.qkv, cos, sin, positions, slots, kcache, vcache, Hq=self.Hq, Hkv=self.Hkv, D=self.D, q_out=self.q)
+        # projection, rotary embedding and cache write: one launch up to 4 tokens, the two launches beyond (same bits)
+        lib.qkv_rope_kv_write(self.h1, w["wqkv"], w.get("bqkv"), cos, sin, positions, slots, kcache, vcache, Hq=self.Hq,
+                              Hkv=self.Hkv, D=self.D, q_out=self.q, qkv_scratch=self.qkv)
         need = lib.paged_attn_workspace_bytes(T, self.Hq, self.D, max_ctx)
         if need and (self.attn_ws is None or self.attn_ws.numel() < need):
             self.attn_ws = torch.empty(need, dtype=torch.uint8, device=self.q.device)

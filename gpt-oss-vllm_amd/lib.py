@@ -30,6 +30,7 @@ EXPORTS = (
     "m355_repack_nf4_ex", "m355_moe_nf4_forward_ex", "m355_moe_nf4_forward_q8", "m355_repack_absmax_u8",
     "m355_moe_nf4_forward_routed", "m355_attn_prefill", "m355_moe_combine_add_rmsnorm", "m355_init",
     "m355_moe_nf4_forward_static", "m355_router_topk_ep_pack", "m355_moe_nf4_forward_ep_rows", "m355_ep_reduce_add_rmsnorm",
+    "m355_qkv_rope_kv_write",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -106,6 +107,8 @@ def load() -> ctypes.CDLL:
     L.m355_moe_combine_add_rmsnorm.argtypes = [vp, sz, i32, i32, i32, i32, vp, i32, vp, vp, ctypes.c_float, i32, vp, vp, vp]
     L.m355_moe_combine_add_rmsnorm.restype = i32
     L.m355_rope_kv_write.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
+    L.m355_qkv_rope_kv_write.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.m355_qkv_rope_kv_write.restype = i32
     for fn in ("m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce", "m355_nf4_dequant", "m355_repack_nf4", "m355_router_topk", "m355_topk_softmax",
                "m355_moe_nf4_forward", "m355_paged_attn_decode", "m355_add_rmsnorm", "m355_rope_kv_write"):
         getattr(L, fn).restype = i32
@@ -572,6 +575,33 @@ def rope_kv_write(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, posit
                                      _dev(slots, torch.int64, "slots"), T, Hq, Hkv, D, kcache.shape[1], cos.shape[0],
                                      _dev(q_out, torch.float16, "q_out"), _dev(kcache, torch.float16, "kcache"),
                                      _dev(vcache, torch.float16, "vcache"), _stream()), "m355_rope_kv_write")
+    return q_out
+
+
+def qkv_rope_kv_write(x: torch.Tensor, wqkv: torch.Tensor, bqkv: Optional[torch.Tensor], cos: torch.Tensor, sin: torch.Tensor,
+                      positions: torch.Tensor, slots: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, *, Hq: int,
+                      Hkv: int, D: int, q_out: Optional[torch.Tensor] = None, qkv_scratch: Optional[torch.Tensor] = None):
+    """The q/k/v projection of x [T][K] followed by rope_kv_write on its result, in one call (one launch up to 4 tokens;
+    beyond, the two launches through qkv_scratch [T][(Hq + 2 Hkv) D], allocated here when missing).  The bits of
+    linear_f16 then rope_kv_write.  m355_qkv_rope_kv_write."""
+    T, K = x.shape
+    N = (Hq + 2 * Hkv) * D
+    if wqkv.shape != (N, K):
+        raise ValueError(f"wqkv is {tuple(wqkv.shape)}, expected {(N, K)}")
+    if cos.shape != sin.shape or cos.shape[1] != D // 2:
+        raise ValueError("cos/sin must be [max_pos][D/2]")
+    if kcache.shape != vcache.shape or kcache.shape[2] != Hkv or kcache.shape[3] != D:
+        raise ValueError("caches must be [blocks][block_size][Hkv][D]")
+    if q_out is None:
+        q_out = torch.empty((T, Hq, D), dtype=torch.float16, device=x.device)
+    if qkv_scratch is None and T > 4:
+        qkv_scratch = torch.empty((T, N), dtype=torch.float16, device=x.device)
+    _check(load().m355_qkv_rope_kv_write(
+        _dev(x, torch.float16, "x"), T, _dev(wqkv, torch.float16, "wqkv"), None if bqkv is None else _dev(bqkv, torch.float16, "bqkv"),
+        K, _dev(cos, torch.float16, "cos"), _dev(sin, torch.float16, "sin"), _dev(positions, torch.int32, "positions"),
+        _dev(slots, torch.int64, "slots"), Hq, Hkv, D, kcache.shape[1], cos.shape[0],
+        None if qkv_scratch is None else _dev(qkv_scratch, torch.float16, "qkv_scratch"), _dev(q_out, torch.float16, "q_out"),
+        _dev(kcache, torch.float16, "kcache"), _dev(vcache, torch.float16, "vcache"), _stream()), "m355_qkv_rope_kv_write")
     return q_out
 
 

@@ -144,6 +144,39 @@ def test_gpu_linear_f16(T, N, K, bias, resid):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,Hq,Hkv,D,K,bias", [(1, 64, 8, 64, 2880, True), (4, 64, 8, 64, 2880, True), (3, 4, 2, 32, 192, False),
+                                               (2, 6, 3, 16, 4096, True), (7, 8, 4, 64, 256, True)])
+def test_gpu_qkv_rope_kv_write_equals_the_two_launches(T, Hq, Hkv, D, K, bias):
+    """m355_qkv_rope_kv_write (one launch up to 4 tokens) against m355_linear_f16 followed by m355_rope_kv_write: q, and
+    every word of both caches (a token with a negative slot writes nothing), bit for bit."""
+    from gpt_oss_vllm_amd import lib
+    cuda = torch.device("cuda:0")
+    sd = oracle_ref.stream_seed(720, T, Hq, K)
+    N, block_size, nblocks, max_pos = (Hq + 2 * Hkv) * D, 16, 5, 40
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    x = dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 1), (T, K)))
+    w = dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 2), (N, K), 0.03))
+    b = dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 3), (N,), 0.2)) if bias else None
+    cos = dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 4), (max_pos, D // 2)))
+    sin = dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 5), (max_pos, D // 2)))
+    positions = torch.tensor([(7 * t + 3) % max_pos for t in range(T)], dtype=torch.int32, device=cuda)
+    slots = torch.tensor([(11 * t + 5) % (nblocks * block_size) if t != 1 else -1 for t in range(T)], dtype=torch.int64, device=cuda)
+    outs = []
+    for fused in (False, True):
+        kc = torch.full((nblocks, block_size, Hkv, D), 7.0, dtype=torch.float16, device=cuda)
+        vc = torch.full((nblocks, block_size, Hkv, D), 7.0, dtype=torch.float16, device=cuda)
+        if fused:
+            q = lib.qkv_rope_kv_write(x, w, b, cos, sin, positions, slots, kc, vc, Hq=Hq, Hkv=Hkv, D=D)
+        else:
+            q = lib.rope_kv_write(lib.linear_f16(x, w, b), cos, sin, positions, slots, kc, vc, Hq=Hq, Hkv=Hkv, D=D)
+        outs.append((q, kc, vc))
+    torch.cuda.synchronize()
+    for a, c in zip(outs[0], outs[1]):
+        assert torch.equal(a.view(torch.int16), c.view(torch.int16))
+    assert not (outs[1][1] == 7.0).all()
+
+
+@pytest.mark.gpu
 def test_gpu_linear_f16_prompt_size():
     """8192 tokens through the q/k/v projection shape (256-token tiles): sampled tokens against an fp32 matmul, and
     the result is the same whatever else shares the launch (a token's row alone through the small-batch kernel)."""
