@@ -845,6 +845,17 @@ def main():
         },
     }
 
+    if sharded:
+        # what the collective library saw, so a line from an N-GPU run shows that N ranks really took part
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as exc:                                       # the version query is informative only
+            rccl = f"unknown ({type(exc).__name__})"
+        result["config"]["rccl_ranks"] = dist.get_world_size()
+        result["config"]["rccl_version"] = rccl
+        result["config"]["exchange"] = ("all_to_all_single of full-capacity chunks: every rank ships "
+                                        f"{a.batch_per_gpu} token rows to every peer (dispatch and return), empty rows included")
+
     def attempt(key, fn):
         """A leg beside the headline measurement: if it fails, the line is still printed and carries the failure in the
         leg's place (the traceback goes to stderr)."""

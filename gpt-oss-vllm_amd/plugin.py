@@ -175,9 +175,11 @@ class Mi355Nf4MoEConfig(_QConfigBase):
     LAYOUTS = ("reference", "true_bnb")
     GATE_UP_ORDERS = ("concat", "interleaved")
     ABSMAX_STORAGE = ("auto", "fp32")
+    PREFIX_FILTERS = ("experts", "reference")
+    REFERENCE_PREFIX_PARTS = ("w13", "w2", "gate", "up", "down")   # patches/bnb_moe_4bit.py:46
 
     def __init__(self, layout: str = "reference", gate_up_order: str = "concat", absmax_storage: str = "auto",
-                 max_tokens: int = 0):
+                 max_tokens: int = 0, prefix_filter: str = "experts"):
         """layout "reference": tensors are read as the reference's loader reads them (low nibble first, mean
         fallback for the nested scales, no offset) -- the parity contract.  "true_bnb": as bitsandbytes wrote
         them (high nibble first, one nested scale per 256 blocks, plus nested_offset)."""
@@ -188,7 +190,13 @@ class Mi355Nf4MoEConfig(_QConfigBase):
             raise ValueError(f"gate_up_order {gate_up_order!r}: expected one of {self.GATE_UP_ORDERS}")
         if absmax_storage not in self.ABSMAX_STORAGE:
             raise ValueError(f"absmax_storage {absmax_storage!r}: expected one of {self.ABSMAX_STORAGE}")
+        if prefix_filter not in self.PREFIX_FILTERS:
+            raise ValueError(f"prefix_filter {prefix_filter!r}: expected one of {self.PREFIX_FILTERS}")
         self.layout = layout
+        # "experts": every layer whose prefix names experts gets the method (a FusedMoE layer's prefix is
+        # "...mlp.experts", without a projection name).  "reference": the reference's own rule, which also wants one
+        # of w13/w2/gate/up/down in the prefix (patches/bnb_moe_4bit.py:46), for callers that ask per projection.
+        self.prefix_filter = prefix_filter
         # tokens per forward the workspace is sized for when the weights are converted (vLLM: max_num_batched_tokens);
         # 0 = grow on demand outside graph capture
         self.max_tokens = int(max_tokens)
@@ -224,7 +232,8 @@ class Mi355Nf4MoEConfig(_QConfigBase):
     def from_config(cls, config: Dict[str, Any]) -> "Mi355Nf4MoEConfig":
         config = config or {}
         return cls(layout=config.get("layout", "reference"), gate_up_order=config.get("gate_up_order", "concat"),
-                   absmax_storage=config.get("absmax_storage", "auto"), max_tokens=int(config.get("max_tokens", 0)))
+                   absmax_storage=config.get("absmax_storage", "auto"), max_tokens=int(config.get("max_tokens", 0)),
+                   prefix_filter=config.get("prefix_filter", "experts"))
 
     def get_scaled_act_names(self) -> List[str]:
         return []
@@ -233,9 +242,11 @@ class Mi355Nf4MoEConfig(_QConfigBase):
         """The method object for expert layers, None for everything else (router, attention stay fp16).
         The reference answers with the string "bnb_4bit" for prefixes that name experts (:43-48); FusedMoE
         needs an object with create_weights/apply, which is what is returned here."""
-        if "experts" in prefix:
-            return Mi355Nf4MoEMethod(self)
-        return None
+        if "experts" not in prefix:
+            return None
+        if self.prefix_filter == "reference" and not any(part in prefix for part in self.REFERENCE_PREFIX_PARTS):
+            return None
+        return Mi355Nf4MoEMethod(self)
 
 
 def is_moe_weight(name: str) -> bool:

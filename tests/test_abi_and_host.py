@@ -57,6 +57,14 @@ def test_config_surface_mirrors_reference():
     assert cfg.get_quant_method(None, "model.layers.3.attn.qkv") is None          # attention stays fp16
     assert cfg.get_quant_method(None, "model.layers.3.mlp.router") is None        # router stays fp16
     assert isinstance(cfg.get_quant_method(None, "model.layers.3.mlp.experts"), plugin.Mi355Nf4MoEMethod)
+    # the reference's own prefix rule (patches/bnb_moe_4bit.py:46) as an option: experts AND a projection name
+    strict = plugin.Mi355Nf4MoEConfig.from_config({"prefix_filter": "reference"})
+    assert strict.get_quant_method(None, "model.layers.3.mlp.experts") is None
+    assert strict.get_quant_method(None, "model.layers.3.attn.qkv") is None
+    for tail in ("w13_weight", "w2_weight", "gate_up_proj", "down_proj"):
+        assert isinstance(strict.get_quant_method(None, "model.layers.3.mlp.experts." + tail), plugin.Mi355Nf4MoEMethod)
+    with pytest.raises(ValueError):
+        plugin.Mi355Nf4MoEConfig(prefix_filter="all")
     assert plugin.is_moe_weight("model.layers.0.mlp.experts.w13_weight")
     assert plugin.is_moe_weight("model.layers.0.mlp.experts.gate_up_projs.3.weight")
     assert not plugin.is_moe_weight("model.layers.0.attn.qkv.weight")
