@@ -242,7 +242,8 @@ def median(v):
 def roofline_gate_up(stepper, reps=5):
     """Average duration of the streaming kernel's gate_up launches (HIP events on the launch stream, layers cycled so the
     weights come from HBM) against the algorithmic bytes of the experts each launch streams.  `gate_up` is the launch as
-    the step runs it: the (token, k) pairs are bucketed inside it, and for up to 8 tokens it computes the router too;
+    the step runs it: the (token, k) pairs are bucketed inside it, and for up to 24 tokens it first picks the top-k from
+    the router logits (which a launch of their own has left in the workspace: not part of this figure);
     `gate_up_given_routing` is the same launch handed finished routing lists (nothing in front of its first weight
     load), `down` the down launch alone (in the step, small batches also combine inside it)."""
     lib = stepper.lib
@@ -256,17 +257,21 @@ def roofline_gate_up(stepper, reps=5):
     torch.cuda.synchronize()
     active = stepper.active_experts_per_layer()
     res = {}
+    topk_inside = stepper.batch <= 24     # the step's entry point then leaves the top-k to the gate_up launch
     for lay in stepper.L:   # every layer owns a workspace: leave its routing (and h for the down GEMM) in place
         ep = lay["ep"]
         lay["_args"] = dict(E_local=ep.epr, e_first=0, H=H, FF=FF, workspace=ep.workspace, out=lay["out"])
-        lib.moe_nf4_forward(lay["x"], lay["ids"], lay["w"], *ep.weights, flags=F | lib.FLAG_SKIP_COMBINE, **lay["_args"])
+        if topk_inside:     # gate_up only: the router logits stay in the workspace (the down stage would overwrite them)
+            lib.moe_nf4_forward_routed(lay["x"], lay["wr"], None, TOPK, *ep.weights, ids=lay["ids"], w=lay["w"],
+                                       flags=gate_up_as_run, **lay["_args"])
+        else:
+            lib.moe_nf4_forward(lay["x"], lay["ids"], lay["w"], *ep.weights, flags=F | lib.FLAG_SKIP_COMBINE, **lay["_args"])
     torch.cuda.synchronize()
-    router_inside = stepper.batch <= 8     # the step then calls the entry point that computes the router in the gate_up launch
 
     def as_run(lay):
-        if router_inside:
+        if topk_inside:
             lib.moe_nf4_forward_routed(lay["x"], lay["wr"], None, TOPK, *lay["ep"].weights, ids=lay["ids"], w=lay["w"],
-                                       flags=gate_up_as_run, **lay["_args"])
+                                       flags=gate_up_as_run | lib.FLAG_LOGITS_READY, **lay["_args"])
         else:
             lib.moe_nf4_forward(lay["x"], lay["ids"], lay["w"], *lay["ep"].weights, flags=gate_up_as_run, **lay["_args"])
 
@@ -883,7 +888,8 @@ def main():
         if rank == 0 and world == 1 and not a.no_roofline:
             bs1.graph = None
             r1, act1 = roofline_gate_up(bs1)
-            out["roofline_gate_up"] = {"kernel": "moe_gemm_stream_kernel<gate_up, route = inline + router>: the launch as the step runs it",
+            out["roofline_gate_up"] = {"kernel": "moe_gemm_stream_kernel<gate_up, route = top-k + inline>: the launch as the step runs it (top-k of the "
+                                                 "finished router logits and bucketing of the pairs inside)",
                                        "achieved": r1["gate_up"]["gbs"], "frac": r1["gate_up"]["gbs"] / HBM_PEAK_GBS,
                                        "avg_us": r1["gate_up"]["avg_us"], "launch_alone_us": r1["gate_up"]["alone_us"],
                                        "given_routing": {"avg_us": r1["gate_up_given_routing"]["avg_us"],

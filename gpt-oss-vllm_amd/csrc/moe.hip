@@ -422,6 +422,16 @@ __device__ __forceinline__ void gemm_epilogue_y2(float sum0, float sum1, half_t*
     else *reinterpret_cast<half2_t*>(dst) = v;
 }
 
+// Router logits of a decode batch on every CU: one wave per (token, 4 experts), so that no CU has to pull the whole
+// router matrix through its own L1 (a workgroup per token does, and at a few dozen tokens that sets the router's time).
+// The top-k of a token needs all its logits: the gate_up launch that follows picks it (INLINE == 2).
+__global__ __launch_bounds__(64) void router_logits_kernel(const half_t* __restrict__ x, int64_t x_stride,
+                                                           const half_t* __restrict__ wr, const half_t* __restrict__ br,
+                                                           int H, int E, half_t* __restrict__ logits) {
+    const int t = blockIdx.y;
+    router_logits_wave(x + (int64_t)t * x_stride, wr, br, H, E, 4 * (int)blockIdx.x, nullptr, logits + (int64_t)t * E);
+}
+
 // What a gate_up launch needs to bucket the (token, k) pairs by expert itself (INLINE), instead of reading the lists
 // a routing kernel left in the workspace: the raw expert ids, and where workgroup 0 leaves the lists for the kernels
 // that follow (down GEMM, combine).
@@ -430,15 +440,16 @@ struct RouteIO {
     int ids_stride;   // int32 between the picks of one token and the next (k: dense)
     int P, E_local, e_first;
     int32_t *n_active, *offsets, *active, *sorted, *inv, *n_tiles, *tile_expert, *tile_m0;
-    // INLINE == 2: the launch also computes the router (logits, top-k, softmax) for its few tokens, every workgroup
-    // for itself; workgroup 0 leaves ids and weights in ids_out / w_out for the combine
-    const half_t *r_x, *r_wr, *r_br;
-    int r_H, r_E, r_k;
+    // INLINE == 2: the logits [T][r_E] (fp16) were left by router_logits_kernel; every workgroup picks the top-k of r_k
+    // itself, and workgroup 0 leaves ids and weights in ids_out / w_out for the combine and the caller
+    const half_t* r_logits;
+    int r_E, r_k;
     int32_t* ids_out;
     float* w_out;
 };
-constexpr int FUSE_ROUTER_MAX_T = 8;     // tokens up to which gate_up computes the router itself
-constexpr int FUSE_ROUTER_MAX_E = 256;   // global experts: the logits of all tokens must fit the reduction buffers
+constexpr int SPLIT_ROUTER_MAX_T = 24;    // tokens up to which gate_up picks the top-k from finished logits (beyond, the picking
+                                          // in front of every workgroup's first load costs more than the router kernel's launch)
+constexpr int SPLIT_ROUTER_MAX_E = 256;   // global experts: a row of logits per wave must fit the reduction buffers
 constexpr int INLINE_MAX_P = 256;      // one pair per thread of the smallest workgroup
 constexpr int INLINE_MAX_E = 128;      // two experts per lane of the scanning wave
 constexpr int INLINE_MAX_TILES = 160;  // <= min(P, E) when T <= 16, else <= E + P / 16
@@ -547,7 +558,7 @@ __device__ __forceinline__ void build_lutp(uint32_t* lut, int tid) {
     lds_barrier();
 }
 
-// INLINE 0: routing lists from the workspace, 1: pairs bucketed here, 2: router too.  KP: K-parts per row-tile pair (the
+// INLINE 0: routing lists from the workspace, 1: pairs bucketed here, 2: top-k picked from finished logits, then bucketed.  KP: K-parts per row-tile pair (the
 // waves that share an item's rows; each holds 48 / KP blocks of the item in registers).  NT: 16-token sets per token tile
 // (a tile of 16 NT tokens shares one pass over the weights; NT = 2 needs the shorter K-parts of KP = 8 to keep both
 // sets' activations in registers).
@@ -580,22 +591,48 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
     uint32_t* lut = reinterpret_cast<uint32_t*>(smem);
     unsigned char* red = smem + LUTP_BYTES;
     InlineTables* rt = reinterpret_cast<InlineTables*>(red + RED_ALL);
+    static_assert(INLINE != 2 || INLINE_MAX_P * 8 + PAIRS * KP * SPLIT_ROUTER_MAX_E * 4 <= RED_ALL, "picks and a row of logits per wave");
     int te_lane = 0;
     if constexpr (INLINE) {
         // the ids are requested first; the code table is built later, while the first weights are on their way
         int my_e = -1;
         if constexpr (INLINE == 2) {
-            // router of the launch's few tokens, computed by every workgroup with the router kernel's own code (same
-            // bits): logits [T][E] and the picks live in the reduction buffers until the pairs are bucketed
+            // The logits come from router_logits_kernel (every CU, a wave per token and 4 experts).  Every workgroup picks
+            // the top-k of all tokens itself, a wave taking every (PAIRS * KP)-th token, with the router kernel's own code
+            // (same bits): up to 64 experts from a lane per expert, beyond from a row of LDS per wave.  The picks live in
+            // the reduction buffers until the pairs are bucketed.
             const int Tn = rio.P / rio.r_k;
-            float* lg = reinterpret_cast<float*>(red);
-            float* wl = lg + Tn * rio.r_E;
+            float* wl = reinterpret_cast<float*>(red);
             int32_t* il = reinterpret_cast<int32_t*>(wl + rio.P);
-            for (int t = 0; t < Tn; t++)
-                router_logits_wg<PAIRS * KP>(rio.r_x + (int64_t)t * rio.r_H, rio.r_wr, rio.r_br, rio.r_H, rio.r_E, lg + t * rio.r_E, nullptr);
-            M355_PRO_STAMP(3)   /* router logits computed */
-            __syncthreads();
-            for (int t = threadIdx.x >> 6; t < Tn; t += PAIRS * KP) topk_softmax_wave(lg + t * rio.r_E, rio.r_E, rio.r_k, il + t * rio.r_k, wl + t * rio.r_k);
+            const int wv_ = (int)threadIdx.x >> 6, ln_ = (int)threadIdx.x & 63;
+            constexpr int NW = PAIRS * KP;
+            if (rio.r_E <= 64) {
+                constexpr int PER = 4;   // a wave's tokens four at a time, their logits requested together
+                for (int t0 = wv_; t0 < Tn; t0 += PER * NW) {
+                    float mine[PER];
+#pragma unroll
+                    for (int j = 0; j < PER; j++) {
+                        const int t = t0 + j * NW;
+                        mine[j] = (t < Tn && ln_ < rio.r_E) ? (float)rio.r_logits[(int64_t)t * rio.r_E + ln_] : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < PER; j++) {
+                        const int t = t0 + j * NW;
+                        if (t < Tn) topk_softmax_wave64(mine[j], rio.r_E, rio.r_k, il + t * rio.r_k, wl + t * rio.r_k);
+                    }
+                }
+            } else {
+                float* lg = reinterpret_cast<float*>(il + rio.P) + wv_ * rio.r_E;   // (SPLIT_ROUTER_MAX_E floats per wave fit)
+                for (int t = wv_; t < Tn; t += NW) {
+                    for (int e = ln_; e < rio.r_E; e += 64) lg[e] = (float)rio.r_logits[(int64_t)t * rio.r_E + e];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    topk_softmax_wave(lg, rio.r_E, rio.r_k, il + t * rio.r_k, wl + t * rio.r_k);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            M355_PRO_STAMP(3)   /* picks made */
             __syncthreads();
             if ((int)threadIdx.x < rio.P) {
                 my_e = il[threadIdx.x] - rio.e_first;
@@ -1269,17 +1306,25 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
 
     // gate_up buckets the pairs itself when it can; the routing kernel runs when it cannot, or when gate_up is skipped
     const bool inline_route = !tiled && !wide && can_route_inline(P, E_local, H) && !(flags & M355_FLAG_SKIP_GATE_UP);
-    // The router: inside the gate_up launch for a handful of tokens (saves a launch and its wait), else its own launch
-    const bool fuse_router = router.wr && inline_route && T <= FUSE_ROUTER_MAX_T && router.E_global <= FUSE_ROUTER_MAX_E &&
-                             !(flags & M355_FLAG_SKIP_ROUTE);
-    if (router.wr && !fuse_router && !(flags & M355_FLAG_SKIP_ROUTE)) {
+    // The router of a small batch: the logits as a launch of their own that uses every CU, the top-k inside gate_up (a
+    // workgroup per token, as m355_router_topk runs it, pulls the whole router matrix through one CU's L1).  The logits lie
+    // in the y rows, which nothing touches before the down stage.
+    const bool split_router = router.wr && inline_route && T <= SPLIT_ROUTER_MAX_T && router.E_global <= SPLIT_ROUTER_MAX_E &&
+                              (int64_t)T * router.E_global <= (int64_t)P * H &&
+                              !(flags & (M355_FLAG_SKIP_ROUTE | M355_FLAG_ROUTER_LAUNCH));
+    if (split_router) {
+        if (!(flags & M355_FLAG_LOGITS_READY)) {
+            router_logits_kernel<<<dim3((router.E_global + 3) / 4, T), dim3(64), 0, st>>>(
+                (const half_t*)x_f16, rows.x_stride, (const half_t*)router.wr, (const half_t*)router.br, H, router.E_global, ws.y);
+            M355_LAUNCH_CHECK("router_logits_kernel");
+        }
+    } else if (router.wr && !(flags & M355_FLAG_SKIP_ROUTE)) {
         if (int rc = m355_router_topk(x_f16, router.wr, router.br, T, H, router.E_global, k, const_cast<int32_t*>(ids),
                                       const_cast<float*>(w), nullptr, stream))
             return rc;
     }
     const RouteIO rio = {ids, rows.ids_stride, P, E_local, e_first, ws.n_active, ws.offsets, ws.active, ws.sorted, ws.inv, ws.n_tiles, ws.tile_expert, ws.tile_m0,
-                         (const half_t*)x_f16, (const half_t*)router.wr, (const half_t*)router.br, H, router.E_global, k,
-                         const_cast<int32_t*>(ids), const_cast<float*>(w)};
+                         ws.y, router.E_global, k, const_cast<int32_t*>(ids), const_cast<float*>(w)};
     if (!(flags & M355_FLAG_SKIP_ROUTE) && !inline_route) {
         moe_route_kernel<<<dim3(1), dim3(ROUTE_THREADS), 0, st>>>(ids, rows.ids_stride, k, P, E_local, e_first, ws.n_active, ws.offsets,
                                                                   ws.active, ws.sorted, ws.inv, mt_rows, ws.n_tiles,
@@ -1307,7 +1352,7 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
     const CombineIO cio_dn = {fold_combine ? (half_t*)out_f16 : nullptr, ws.inv, w, rows.w_stride, T,
                               (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0, ws.pg_done};
     if (!tiled && !(flags & M355_FLAG_SKIP_GATE_UP)) {
-        if (int rc = fuse_router    ? launch_gemm<0, 2>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table, cio_gu)
+        if (int rc = split_router   ? launch_gemm<0, 2>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table, cio_gu)
                      : inline_route ? launch_gemm<0, 1>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table, cio_gu)
                                     : launch_gemm<0, 0>((const half_t*)x_f16, w13_q, w13_absmax, ws, H, 2 * FF, k, mt_rows, slots, ws.h, cus, st, rio, sp13, a13.u8, a13.table, cio_gu))
             return rc;

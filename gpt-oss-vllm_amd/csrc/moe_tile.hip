@@ -21,7 +21,10 @@
 namespace m355 {
 
 
-constexpr int TG_WAVES = 8;                      // two waves per SIMD
+#ifndef TG_WAVES_N
+#define TG_WAVES_N 8
+#endif
+constexpr int TG_WAVES = TG_WAVES_N;             // 8: two waves per SIMD
 constexpr int TG_THREADS = TG_WAVES * 64;
 constexpr int TG_LUT_BYTES = 256 * 256;          // half2 per byte value, 32 replicas of 4 B in a 256-byte row
 // The kernel is a template over RT, the row-tile pairs (32 weight rows each) a wave owns, and NTT, the 16-token tiles of
@@ -37,7 +40,10 @@ constexpr int TG_LUT_BYTES = 256 * 256;          // half2 per byte value, 32 rep
 #define TG_FORM_RT 1
 #endif
 constexpr int TG_DEFAULT_RT = TG_FORM_RT;
-constexpr int TG_DEFAULT_NTT = 16 / TG_FORM_RT;
+#ifndef TG_FORM_NTT
+#define TG_FORM_NTT (16 / TG_FORM_RT)
+#endif
+constexpr int TG_DEFAULT_NTT = TG_FORM_NTT;
 template <int RT, int NTT>
 struct TileForm {
     static constexpr int ROWS = 16 * NTT;                        // tokens per token tile

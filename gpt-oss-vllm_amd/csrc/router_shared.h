@@ -27,16 +27,29 @@ __device__ __forceinline__ void wave_argmax(float& v, int& idx) {
     }
 }
 
-// E <= 64: lane e holds logit e; its rank is the number of logits that beat it (larger, or equal with a
-// smaller index), found with E scalar broadcasts; ranks < k are the picks, in order.
+// Sort key of (logit, expert) for unsigned comparison: larger logit first, on equal logits the smaller expert id.  The
+// logit is an exact fp16 number held as fp32 (or -inf), so the low 13 bits of its pattern carry nothing and six of them
+// take 63 - expert; -0 counts as +0, as it does when floats are compared.
+__device__ __forceinline__ uint32_t topk_sort_key(float v, int expert) {
+    uint32_t b = __builtin_bit_cast(uint32_t, v);
+    if (b == 0x80000000u) b = 0u;
+    const uint32_t m = b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);   // monotone in v
+    return (m & ~63u) | (uint32_t)(63 - expert);
+}
+
+// E <= 64: lane e holds logit e (an exact fp16 number); its rank is the number of logits that beat it (larger, or equal
+// with a smaller index), counted on sort keys against one lane broadcast per rival; ranks < k are the picks, in order.
 __device__ __forceinline__ void topk_softmax_wave64(float mine, int E, int k, int32_t* ids_out, float* w_out) {
     const int lane = threadIdx.x & 63;
     const bool valid = lane < E && !(mine != mine);
     const float v = valid ? mine : -INFINITY;
+    const uint32_t key = lane < E ? topk_sort_key(v, lane) : 0u;   // (a lane past E beats nobody: every real key is > 0)
     int rank = 0;
-    for (int e = 0; e < E; e++) {
-        const float o = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), e));
-        rank += (o > v || (o == v && e < lane)) ? 1 : 0;
+#pragma unroll
+    for (int e = 0; e < 32; e++) rank += ((uint32_t)__builtin_amdgcn_readlane((int)key, e) > key) ? 1 : 0;
+    if (E > 32) {
+#pragma unroll
+        for (int e = 32; e < 64; e++) rank += ((uint32_t)__builtin_amdgcn_readlane((int)key, e) > key) ? 1 : 0;
     }
     if (lane >= E) rank = 64;
     const unsigned long long top = __ballot(rank == 0);
@@ -87,53 +100,60 @@ __device__ __forceinline__ void topk_softmax_wave(float* logit, int E, int k, in
     }
 }
 
-// logit_out[e] (LDS, fp32 holding exact fp16 values) = fp16(x_row . wr[e] + br[e]) for e in [0, E), computed by the
-// NW waves of the calling workgroup: a wave takes 4 experts at a time and each 16-byte piece of x once per 4 experts,
-// six pieces per lane requested before any is used.  The caller synchronises the workgroup before reading logit_out.
+// The logits of experts e0 .. e0 + 3 of one token, by one wave: logit_out[e] (fp32 holding exact fp16 values; LDS or
+// null) = fp16(x_row . wr[e] + br[e]), also stored to logits_global[e] (fp16) when given.  Each 16-byte piece of x is
+// read once per 4 experts, six pieces per lane requested before any is used.
+__device__ __forceinline__ void router_logits_wave(const half_t* __restrict__ x_row, const half_t* __restrict__ wr,
+                                                   const half_t* __restrict__ br, int H, int E, int e0, float* logit_out,
+                                                   half_t* __restrict__ logits_global) {
+    const int lane = threadIdx.x & 63;
+    const int chunks = H / 8;
+    const u32x4_t* xr = reinterpret_cast<const u32x4_t*>(x_row);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 6;
+    for (int cbase = 0; cbase < chunks; cbase += 64 * U) {
+        u32x4_t xv[U], wv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int c = min(cbase + u * 64 + lane, chunks - 1);
+            xv[u] = xr[c];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int e = (e0 + i < E) ? e0 + i : E - 1;
+                wv[u][i] = reinterpret_cast<const u32x4_t*>(wr + (int64_t)e * H)[c];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (cbase + u * 64 + lane < chunks) {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc[i] = __builtin_amdgcn_fdot2(as_half2(xv[u][j]), as_half2(wv[u][i][j]), acc[i], false);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float s = wave_sum(acc[i]);
+        if (lane == 0 && e0 + i < E) {
+            const float full = s + (br ? (float)br[e0 + i] : 0.f);
+            const half_t l16 = (half_t)full;   // the reference's router output is an fp16 tensor
+            if (logit_out) logit_out[e0 + i] = (float)l16;
+            if (logits_global) logits_global[e0 + i] = l16;
+        }
+    }
+}
+
+// All E logits of one token by the NW waves of the calling workgroup, a wave taking 4 experts at a time.  The caller
+// synchronises the workgroup before reading logit_out.
 template <int NW>
 __device__ __forceinline__ void router_logits_wg(const half_t* __restrict__ x_row, const half_t* __restrict__ wr,
                                                  const half_t* __restrict__ br, int H, int E, float* logit_out,
                                                  half_t* __restrict__ logits_global) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int chunks = H / 8;
-    const u32x4_t* xr = reinterpret_cast<const u32x4_t*>(x_row);
-    for (int e0 = wave * 4; e0 < E; e0 += NW * 4) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        constexpr int U = 6;
-        for (int cbase = 0; cbase < chunks; cbase += 64 * U) {
-            u32x4_t xv[U], wv[U][4];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int c = min(cbase + u * 64 + lane, chunks - 1);
-                xv[u] = xr[c];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int e = (e0 + i < E) ? e0 + i : E - 1;
-                    wv[u][i] = reinterpret_cast<const u32x4_t*>(wr + (int64_t)e * H)[c];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                if (cbase + u * 64 + lane < chunks) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            acc[i] = __builtin_amdgcn_fdot2(as_half2(xv[u][j]), as_half2(wv[u][i][j]), acc[i], false);
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float s = wave_sum(acc[i]);
-            if (lane == 0 && e0 + i < E) {
-                const float full = s + (br ? (float)br[e0 + i] : 0.f);
-                const half_t l16 = (half_t)full;   // the reference's router output is an fp16 tensor
-                logit_out[e0 + i] = (float)l16;
-                if (logits_global) logits_global[e0 + i] = l16;
-            }
-        }
-    }
+    const int wave = threadIdx.x >> 6;
+    for (int e0 = wave * 4; e0 < E; e0 += NW * 4) router_logits_wave(x_row, wr, br, H, E, e0, logit_out, logits_global);
 }
 
 }  // namespace m355

@@ -20,6 +20,7 @@ FLAG_FP16_COMBINE = 1
 FLAG_SKIP_ROUTE, FLAG_SKIP_GATE_UP, FLAG_SKIP_DOWN, FLAG_SKIP_COMBINE = 0x100, 0x200, 0x400, 0x800
 FLAG_FORCE_STREAM, FLAG_FORCE_TILE, FLAG_STREAM_WIDE, FLAG_SEPARATE_COMBINE = 0x1000, 0x2000, 0x4000, 0x8000
 FLAG_FOLD_COMBINE = 0x10000
+FLAG_ROUTER_LAUNCH, FLAG_LOGITS_READY = 0x20000, 0x40000
 
 # every symbol include/m355.h declares
 EXPORTS = (
@@ -349,7 +350,8 @@ def moe_nf4_forward_routed(x, wr, br, k: int, w13_q, w13_absmax, w2_q, w2_absmax
                            b13: Optional[torch.Tensor] = None, b2: Optional[torch.Tensor] = None, alpha: float = 1.702,
                            limit: float = 7.0):
     """Router (x @ wr.T + br -> top-k -> softmax) and the MoE layer in one call; ids [T][k] and w [T][k] receive the
-    routing (the bits router_topk gives).  Up to 8 tokens the gate_up launch computes the router itself.
+    routing (the bits router_topk gives).  Up to 24 tokens the logits are a launch of their own over every CU and the
+    gate_up launch picks the top-k (FLAG_ROUTER_LAUNCH: router_topk in front, as beyond 24 tokens).
     Returns (out, ids, w).  m355_moe_nf4_forward_routed."""
     T, E_global = x.shape[0], wr.shape[0]
     if ids is None:

@@ -57,6 +57,13 @@ typedef void* m355_stream_t; /* a hipStream_t (NULL = the default stream) */
    bits every way. */
 #define M355_FLAG_SEPARATE_COMBINE 0x8000
 #define M355_FLAG_FOLD_COMBINE 0x10000
+/* m355_moe_nf4_forward_routed up to 24 tokens computes the router logits as a launch of its own that uses every CU (a
+   wave per token and 4 experts) and picks the top-k inside the gate_up launch, instead of running m355_router_topk (a
+   workgroup per token) in front.  ROUTER_LAUNCH keeps m355_router_topk; same bits either way.  LOGITS_READY (profiling
+   aid): the logits of these tokens are still in the workspace from an earlier call that ran with M355_FLAG_SKIP_DOWN;
+   the logits launch is left out. */
+#define M355_FLAG_ROUTER_LAUNCH 0x20000
+#define M355_FLAG_LOGITS_READY 0x40000
 
 M355_API int m355_version(void);
 M355_API const char* m355_last_error(void);
@@ -167,9 +174,9 @@ M355_API int m355_moe_nf4_forward_q8(const void* x_f16, int T, const int32_t* id
                                      void* out_f16, m355_stream_t stream);
 /* Router and experts in one call: ids_out [T][k] / w_out [T][k] receive what m355_router_topk(x, wr, br) gives (same
  * bits), then the layer runs as m355_moe_nf4_forward_ex / _q8 would (absmax: pass either the fp32 pointers or, with
- * w13_absmax == NULL, the byte form).  Up to 8 tokens (and 256 global experts) the gate_up launch computes the router
- * itself, every workgroup with the router kernel's own code, so a decode step of few sequences spends one launch less
- * per layer; beyond that the router runs as its own launch.  Takes over the router nn.Linear that
+ * w13_absmax == NULL, the byte form).  Up to 24 tokens (and 256 global experts) the logits are computed by a launch that
+ * spreads them over every CU (a wave per token and 4 experts) and the gate_up launch picks the top-k itself, every
+ * workgroup with the router kernel's own code; beyond that m355_router_topk runs in front.  Takes over the router nn.Linear that
  * patches/monkey_patch_router_fp16.py:6-17 casts to fp16 and the top-k + softmax of
  * patches/unsloth_to_vllm_converter.py:291-292, together with the forward of :282-325. */
 M355_API int m355_moe_nf4_forward_routed(const void* x_f16, int T, const void* wr_f16, const void* br_f16, int E_global,

@@ -42,7 +42,7 @@ def short_name(mangled):
     name = name.replace("_kernel", "")
     stage = {"0": "gate_up", "1": "down"}
     if name == "moe_gemm_stream" and len(args) >= 3:
-        return f"moe_gemm_stream<{stage.get(args[0], args[0])},pairs={args[1]},route={('listed', 'inline', 'inline+router')[int(args[2])]}>"
+        return f"moe_gemm_stream<{stage.get(args[0], args[0])},pairs={args[1]},route={('listed', 'inline', 'topk+inline')[int(args[2])]}>"
     if name in ("moe_tile_gemm", "moe_gemm") and args:
         return f"{name}<{stage.get(args[0], args[0])}>"
     return name + (f"<{','.join(args)}>" if args else "")

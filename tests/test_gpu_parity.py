@@ -574,11 +574,17 @@ def test_moe_tile_kernel_prefill_size(ref, m355, cuda):
                                              (2, 256, 5, True, 256, 192), (40, 8, 2, False, 256, 192)]
                          # every batch size of the fused-router form on the gpt-oss-20b routing shape (32 experts, top-4):
                          # the router's picks and the per-expert pair masks share one LDS buffer in that launch
-                         + [(T, 32, 4, T % 2 == 0, 256, 192) for T in range(2, 9)] + [(5, 32, 4, False, 2880, 2880)])
+                         + [(T, 32, 4, T % 2 == 0, 256, 192) for T in range(2, 9)] + [(5, 32, 4, False, 2880, 2880)]
+                         # logits as a launch of their own, top-k inside gate_up (up to 24 tokens, 256 experts), and around the limits
+                         + [(24, 32, 4, False, 2880, 2880), (25, 32, 4, True, 256, 192), (24, 64, 4, False, 256, 192),
+                            (20, 48, 3, True, 256, 192), (17, 5, 5, False, 256, 192), (24, 65, 4, False, 256, 192),
+                            (13, 128, 4, True, 256, 192), (24, 256, 8, False, 256, 192), (3, 257, 4, False, 256, 192),
+                            (32, 32, 4, False, 2880, 2880)])
 def test_router_and_experts_in_one_call(T, E, k, bias, H, FF, ref, m355, cuda):
     """m355_moe_nf4_forward_routed against router_topk followed by the forward: identical ids, weights and output
-    (up to 8 tokens the gate_up launch computes the router itself with the router kernel's code; beyond, the call
-    launches the router kernel)."""
+    (up to 24 tokens and 256 experts the logits are a launch of their own and the gate_up launch picks the top-k with the
+    router kernel's code, from a lane per expert up to 64 experts and from a row of LDS per wave beyond; past those limits
+    the call launches the router kernel)."""
     sd = ref.stream_seed(T, E, k, 808)
     layer = ref.synth_layer(sd, E, H, FF)
     tl = tiled_layer(m355, layer, E, H, FF, cuda)
@@ -591,6 +597,19 @@ def test_router_and_experts_in_one_call(T, E, k, bias, H, FF, ref, m355, cuda):
     torch.cuda.synchronize()
     assert torch.equal(ids, ids0) and torch.equal(w, w0)
     assert torch.equal(out, want)
+    # the router kept as a launch of its own: the same again
+    out2, ids2, w2 = m355.moe_nf4_forward_routed(x, wr, br, k, *tl, E_local=E, e_first=0, H=H, FF=FF,
+                                                 flags=m355.FLAG_FP16_COMBINE | m355.FLAG_ROUTER_LAUNCH)
+    torch.cuda.synchronize()
+    assert torch.equal(ids2, ids0) and torch.equal(w2, w0) and torch.equal(out2, want)
+    # gate_up alone, then again on the logits the first call left in the workspace (what the bench's roofline leg times)
+    ws = torch.empty(max(256, m355.moe_workspace_bytes(T, k, H, FF, E)), dtype=torch.uint8, device=cuda)
+    part = m355.FLAG_FP16_COMBINE | m355.FLAG_SKIP_DOWN | m355.FLAG_SKIP_COMBINE
+    _, ids3, w3 = m355.moe_nf4_forward_routed(x, wr, br, k, *tl, E_local=E, e_first=0, H=H, FF=FF, workspace=ws, flags=part)
+    _, ids4, w4 = m355.moe_nf4_forward_routed(x, wr, br, k, *tl, E_local=E, e_first=0, H=H, FF=FF, workspace=ws,
+                                              flags=part | m355.FLAG_LOGITS_READY)
+    torch.cuda.synchronize()
+    assert torch.equal(ids3, ids0) and torch.equal(w3, w0) and torch.equal(ids4, ids0) and torch.equal(w4, w0)
     # a shard (local experts 2..) sees the same routing and adds up with the rest as the separate calls do
     if E >= 8:
         sl = slice(2, E)
