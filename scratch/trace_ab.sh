@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for v in "$@"; do
   export M355_LIB_PATH=$GRAFT_REPO_ROOT/scratch/exp/$v.so
   rm -rf gpurun_out/trace_ab_$v
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/trace_ab_$v -- python bench.py --steps 10 --warmup 3 --legs none > gpurun_out/trace_ab_$v.log 2>&1 || { tail -5 gpurun_out/trace_ab_$v.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/trace_ab_$v -- python bench.py --steps 10 --warmup 3 --legs none ${BENCH_EXTRA} > gpurun_out/trace_ab_$v.log 2>&1 || { tail -5 gpurun_out/trace_ab_$v.log; exit 1; }
   f=$(find gpurun_out/trace_ab_$v -name '*kernel_stats.csv' | head -1)
   echo "== $v"
   python3 - "$f" <<'PY'
