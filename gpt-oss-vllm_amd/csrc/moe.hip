@@ -1253,13 +1253,14 @@ struct RouterArg {
     const void* wr;
     const void* br;
     int E_global;
+    const void* logits;   // instead of wr / br: finished logits [T][E_global] fp16 (what a FusedMoE layer is handed)
 };
 
 static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const float* w, int k, const uint8_t* w13_q,
                             AbsmaxArg a13, const uint8_t* w2_q, AbsmaxArg a2, int E_local, int e_first, int H, int FF,
                             int act_mode, int flags, const void* b13_f16, const void* b2_f16, float alpha, float limit,
                             void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream,
-                            RouterArg router = RouterArg{nullptr, nullptr, 0}, RowsArg rows = RowsArg{0, 0, 0}) {
+                            RouterArg router = RouterArg{nullptr, nullptr, 0, nullptr}, RowsArg rows = RowsArg{0, 0, 0}) {
     if (T == 0) return 0;   // an empty batch has no buffers to check
     if (!x_f16 || !ids || !w || !w13_q || !a13.ok() || !w2_q || !a2.ok() || !out_f16)
         return fail(-1, "m355_moe_nf4_forward: null pointer");
@@ -1309,22 +1310,25 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
     // The router of a small batch: the logits as a launch of their own that uses every CU, the top-k inside gate_up (a
     // workgroup per token, as m355_router_topk runs it, pulls the whole router matrix through one CU's L1).  The logits lie
     // in the y rows, which nothing touches before the down stage.
-    const bool split_router = router.wr && inline_route && T <= SPLIT_ROUTER_MAX_T && router.E_global <= SPLIT_ROUTER_MAX_E &&
-                              (int64_t)T * router.E_global <= (int64_t)P * H &&
+    const bool split_router = (router.wr || router.logits) && inline_route && T <= SPLIT_ROUTER_MAX_T &&
+                              router.E_global <= SPLIT_ROUTER_MAX_E && (int64_t)T * router.E_global <= (int64_t)P * H &&
                               !(flags & (M355_FLAG_SKIP_ROUTE | M355_FLAG_ROUTER_LAUNCH));
     if (split_router) {
-        if (!(flags & M355_FLAG_LOGITS_READY)) {
+        if (!router.logits && !(flags & M355_FLAG_LOGITS_READY)) {
             router_logits_kernel<<<dim3((router.E_global + 3) / 4, T), dim3(64), 0, st>>>(
                 (const half_t*)x_f16, rows.x_stride, (const half_t*)router.wr, (const half_t*)router.br, H, router.E_global, ws.y);
             M355_LAUNCH_CHECK("router_logits_kernel");
         }
+    } else if (router.logits && !(flags & M355_FLAG_SKIP_ROUTE)) {
+        if (int rc = m355_topk_softmax(router.logits, T, router.E_global, k, const_cast<int32_t*>(ids), const_cast<float*>(w), stream))
+            return rc;
     } else if (router.wr && !(flags & M355_FLAG_SKIP_ROUTE)) {
         if (int rc = m355_router_topk(x_f16, router.wr, router.br, T, H, router.E_global, k, const_cast<int32_t*>(ids),
                                       const_cast<float*>(w), nullptr, stream))
             return rc;
     }
     const RouteIO rio = {ids, rows.ids_stride, P, E_local, e_first, ws.n_active, ws.offsets, ws.active, ws.sorted, ws.inv, ws.n_tiles, ws.tile_expert, ws.tile_m0,
-                         ws.y, router.E_global, k, const_cast<int32_t*>(ids), const_cast<float*>(w)};
+                         router.logits ? (const half_t*)router.logits : ws.y, router.E_global, k, const_cast<int32_t*>(ids), const_cast<float*>(w)};
     if (!(flags & M355_FLAG_SKIP_ROUTE) && !inline_route) {
         moe_route_kernel<<<dim3(1), dim3(ROUTE_THREADS), 0, st>>>(ids, rows.ids_stride, k, P, E_local, e_first, ws.n_active, ws.offsets,
                                                                   ws.active, ws.sorted, ws.inv, mt_rows, ws.n_tiles,
@@ -1407,7 +1411,25 @@ extern "C" int m355_moe_nf4_forward_routed(const void* x_f16, int T, const void*
                             bytes ? AbsmaxArg{nullptr, w13_absmax_u8, w13_table} : AbsmaxArg{w13_absmax, nullptr, nullptr}, w2_q,
                             bytes ? AbsmaxArg{nullptr, w2_absmax_u8, w2_table} : AbsmaxArg{w2_absmax, nullptr, nullptr},
                             E_local, e_first, H, FF, act_mode, flags, b13_f16, b2_f16, alpha, limit, workspace, ws_bytes,
-                            out_f16, stream, RouterArg{wr_f16, br_f16, E_global});
+                            out_f16, stream, RouterArg{wr_f16, br_f16, E_global, nullptr});
+}
+
+extern "C" int m355_moe_nf4_forward_logits(const void* x_f16, int T, const void* logits_f16, int E_global, int k,
+                                           int32_t* ids_out, float* w_out, const uint8_t* w13_q, const float* w13_absmax,
+                                           const uint8_t* w13_absmax_u8, const float* w13_table, const uint8_t* w2_q,
+                                           const float* w2_absmax, const uint8_t* w2_absmax_u8, const float* w2_table,
+                                           int E_local, int e_first, int H, int FF, int act_mode, int flags,
+                                           const void* b13_f16, const void* b2_f16, float alpha, float limit, void* workspace,
+                                           size_t ws_bytes, void* out_f16, m355_stream_t stream) {
+    if (T != 0 && (!logits_f16 || !ids_out || !w_out)) return fail(-1, "m355_moe_nf4_forward_logits: null pointer");
+    if (T != 0 && (E_global <= 0 || E_global > ROUTER_MAX_E || k > E_global))
+        return fail(-2, "m355_moe_nf4_forward_logits: unsupported router shape E=%d k=%d (E <= %d)", E_global, k, ROUTER_MAX_E);
+    const bool bytes = w13_absmax == nullptr;
+    return moe_forward_impl(x_f16, T, ids_out, w_out, k, w13_q,
+                            bytes ? AbsmaxArg{nullptr, w13_absmax_u8, w13_table} : AbsmaxArg{w13_absmax, nullptr, nullptr}, w2_q,
+                            bytes ? AbsmaxArg{nullptr, w2_absmax_u8, w2_table} : AbsmaxArg{w2_absmax, nullptr, nullptr},
+                            E_local, e_first, H, FF, act_mode, flags, b13_f16, b2_f16, alpha, limit, workspace, ws_bytes,
+                            out_f16, stream, RouterArg{nullptr, nullptr, E_global, logits_f16});
 }
 
 extern "C" int m355_moe_nf4_forward_ep_rows(const void* rows, int NT, int k, const uint8_t* w13_q, const float* w13_absmax,

@@ -31,7 +31,7 @@ EXPORTS = (
     "m355_repack_nf4_ex", "m355_moe_nf4_forward_ex", "m355_moe_nf4_forward_q8", "m355_repack_absmax_u8",
     "m355_moe_nf4_forward_routed", "m355_attn_prefill", "m355_moe_combine_add_rmsnorm", "m355_init",
     "m355_moe_nf4_forward_static", "m355_router_topk_ep_pack", "m355_moe_nf4_forward_ep_rows", "m355_ep_reduce_add_rmsnorm",
-    "m355_qkv_rope_kv_write",
+    "m355_qkv_rope_kv_write", "m355_moe_nf4_forward_logits",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -72,6 +72,9 @@ def load() -> ctypes.CDLL:
     L.m355_moe_nf4_forward_routed.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                               i32, i32, i32, i32, i32, i32, vp, vp, f32, f32, vp, sz, vp, vp]
     L.m355_moe_nf4_forward_routed.restype = i32
+    L.m355_moe_nf4_forward_logits.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                              i32, i32, i32, i32, i32, i32, vp, vp, f32, f32, vp, sz, vp, vp]
+    L.m355_moe_nf4_forward_logits.restype = i32
     L.m355_attn_prefill.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                     f32, vp, i32, vp, vp]
     L.m355_attn_prefill.restype = i32
@@ -379,6 +382,46 @@ def moe_nf4_forward_routed(x, wr, br, k: int, w13_q, w13_absmax, w2_q, w2_absmax
         None if b13 is None else _dev(b13, torch.float16, "b13"), None if b2 is None else _dev(b2, torch.float16, "b2"),
         float(alpha), float(limit), _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
         _dev(out, torch.float16, "out"), _stream()), "m355_moe_nf4_forward_routed")
+    return out, ids, w
+
+
+def moe_nf4_forward_logits(x, logits, k: int, w13_q, w13_absmax, w2_q, w2_absmax, *, E_local: int, e_first: int, H: int,
+                           FF: int, ids: Optional[torch.Tensor] = None, w: Optional[torch.Tensor] = None,
+                           workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                           act_mode: int = ACT_SILU_CONCAT, flags: int = FLAG_FP16_COMBINE,
+                           b13: Optional[torch.Tensor] = None, b2: Optional[torch.Tensor] = None, alpha: float = 1.702,
+                           limit: float = 7.0):
+    """Top-k + softmax over finished router logits [T][E_global] fp16 and the MoE layer in one call; ids [T][k] and
+    w [T][k] receive the routing (the bits topk_softmax gives).  Up to 24 tokens the gate_up launch picks the top-k.
+    Returns (out, ids, w).  m355_moe_nf4_forward_logits."""
+    T, E_global = x.shape[0], logits.shape[-1]
+    if logits.shape[0] != T:
+        raise ValueError(f"logits for {logits.shape[0]} tokens, x for {T}")
+    if ids is None:
+        ids = torch.empty((T, k), dtype=torch.int32, device=x.device)
+    if w is None:
+        w = torch.empty((T, k), dtype=torch.float32, device=x.device)
+    need = moe_workspace_bytes(T, k, H, FF, E_local)
+    if workspace is None:
+        workspace = torch.empty(max(need, 256), dtype=torch.uint8, device=x.device)
+    if out is None:
+        out = torch.empty((T, H), dtype=torch.float16, device=x.device)
+    if isinstance(w13_absmax, tuple) != isinstance(w2_absmax, tuple):
+        raise ValueError("w13_absmax and w2_absmax must both be fp32 tensors or both (codes, table) pairs")
+    if isinstance(w13_absmax, tuple):
+        (c13, t13), (c2, t2) = w13_absmax, w2_absmax
+        a13 = (None, _dev(c13, torch.uint8, "w13_absmax codes"), _dev(t13, torch.float32, "w13 table"))
+        a2 = (None, _dev(c2, torch.uint8, "w2_absmax codes"), _dev(t2, torch.float32, "w2 table"))
+    else:
+        a13 = (_dev(w13_absmax, torch.float32, "w13_absmax"), None, None)
+        a2 = (_dev(w2_absmax, torch.float32, "w2_absmax"), None, None)
+    _check(load().m355_moe_nf4_forward_logits(
+        _dev(x, torch.float16, "x"), T, _dev(logits, torch.float16, "logits"), E_global, k, _dev(ids, torch.int32, "ids"),
+        _dev(w, torch.float32, "w"), _dev(w13_q, torch.uint8, "w13_q"), *a13, _dev(w2_q, torch.uint8, "w2_q"), *a2, E_local,
+        e_first, H, FF, act_mode, flags, None if b13 is None else _dev(b13, torch.float16, "b13"),
+        None if b2 is None else _dev(b2, torch.float16, "b2"), float(alpha), float(limit),
+        _dev(workspace, torch.uint8, "workspace"), workspace.numel(), _dev(out, torch.float16, "out"), _stream()),
+        "m355_moe_nf4_forward_logits")
     return out, ids, w
 
 

@@ -449,7 +449,6 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
         lg = router_logits.reshape(-1, router_logits.shape[-1])
         if lg.dtype != torch.float16:
             lg = lg.to(torch.float16)
-        ids, w = lib.topk_softmax(lg.contiguous(), top_k)
         e_first = self._shard_first_expert(layer, expert_map)
         T = x2.shape[0]
         flags = lib.FLAG_FP16_COMBINE
@@ -460,10 +459,12 @@ class Mi355Nf4MoEMethod(_MoEMethodBase):
         if getattr(layer, "_m355_codes", None) is not None:
             a13 = (layer._m355_codes["w13"], layer._m355_tables["w13"])
             a2 = (layer._m355_codes["w2"], layer._m355_tables["w2"])
-        out = lib.moe_nf4_forward(x2.contiguous(), ids, w, layer.w13_qweight.data, a13,
-                                  layer.w2_qweight.data, a2, E_local=E, e_first=e_first, H=H, FF=FF,
-                                  workspace=ws, act_mode=act_mode, flags=flags, b13=getattr(layer, "_m355_b13", None),
-                                  b2=getattr(layer, "_m355_b2", None))
+        # top-k + softmax over the selected logits and the experts in one library call (a decode batch picks the top-k
+        # inside the first GEMM launch: no launch of its own for it)
+        out, _, _ = lib.moe_nf4_forward_logits(x2.contiguous(), lg.contiguous(), top_k, layer.w13_qweight.data, a13,
+                                               layer.w2_qweight.data, a2, E_local=E, e_first=e_first, H=H, FF=FF,
+                                               workspace=ws, act_mode=act_mode, flags=flags,
+                                               b13=getattr(layer, "_m355_b13", None), b2=getattr(layer, "_m355_b2", None))
         if in_dtype != torch.float16:
             out = out.to(in_dtype)
         return out.reshape(shape)

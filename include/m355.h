@@ -186,6 +186,18 @@ M355_API int m355_moe_nf4_forward_routed(const void* x_f16, int T, const void* w
                                          const float* w2_table, int E_local, int e_first, int H, int FF, int act_mode,
                                          int flags, const void* b13_f16, const void* b2_f16, float alpha, float limit,
                                          void* workspace, size_t ws_bytes, void* out_f16, m355_stream_t stream);
+/* The same for a caller that holds finished router logits [T][E_global] fp16, which is what vLLM's FusedMoE layer hands
+ * its quantisation method (router_logits of FusedMoEMethodBase.apply; the reference's apply is
+ * patches/unsloth_to_vllm_converter.py:282-325, its top-k + softmax :291-292): ids_out / w_out receive what
+ * m355_topk_softmax(logits) gives (same bits), then the layer runs.  Up to 24 tokens the gate_up launch picks the top-k
+ * itself, so the call is two launches (three with a separate combine); beyond, m355_topk_softmax runs in front. */
+M355_API int m355_moe_nf4_forward_logits(const void* x_f16, int T, const void* logits_f16, int E_global, int k,
+                                         int32_t* ids_out, float* w_out, const uint8_t* w13_q, const float* w13_absmax,
+                                         const uint8_t* w13_absmax_u8, const float* w13_table, const uint8_t* w2_q,
+                                         const float* w2_absmax, const uint8_t* w2_absmax_u8, const float* w2_table,
+                                         int E_local, int e_first, int H, int FF, int act_mode, int flags,
+                                         const void* b13_f16, const void* b2_f16, float alpha, float limit, void* workspace,
+                                         size_t ws_bytes, void* out_f16, m355_stream_t stream);
 /*
  * Causal self-attention over whole prompts (prefill), the companion of m355_paged_attn_decode for the tokens that
  * arrive together: q [tokens][Hq][D], k / v [tokens][Hkv][D] fp16 with token strides in elements (so slices of a fused

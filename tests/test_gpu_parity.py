@@ -620,6 +620,31 @@ def test_router_and_experts_in_one_call(T, E, k, bias, H, FF, ref, m355, cuda):
         assert torch.equal(ids_sh, ids0) and torch.equal(o_sh, want_sh)
 
 
+@pytest.mark.parametrize("T,E,k,H,FF", [(1, 32, 4, 2880, 2880), (5, 32, 4, 256, 192), (24, 32, 4, 256, 192), (25, 32, 4, 256, 192),
+                                        (7, 128, 4, 256, 192), (40, 8, 2, 256, 192), (3, 300, 6, 256, 192), (300, 32, 4, 256, 192)])
+def test_logits_and_experts_in_one_call(T, E, k, H, FF, ref, m355, cuda):
+    """m355_moe_nf4_forward_logits (what the plug-in's apply() calls with FusedMoE's router_logits) against
+    m355_topk_softmax followed by the forward: identical ids, weights and output, on a full layer and on a shard."""
+    sd = ref.stream_seed(T, E, k, 909)
+    layer = ref.synth_layer(sd, E, H, FF)
+    tl = tiled_layer(m355, layer, E, H, FF, cuda)
+    x = _to_dev(ref.normal_f16(ref.stream_seed(sd, 1), (T, H)), cuda)
+    lg_h = ref.normal_f16(ref.stream_seed(sd, 2), (T, E), 1.5)
+    lg_h[0, : min(E, 6)] = lg_h[0, 0]          # ties: the lower expert id wins
+    lg = _to_dev(lg_h, cuda)
+    ids0, w0 = m355.topk_softmax(lg, k)
+    want = m355.moe_nf4_forward(x, ids0, w0, *tl, E_local=E, e_first=0, H=H, FF=FF)
+    out, ids, w = m355.moe_nf4_forward_logits(x, lg, k, *tl, E_local=E, e_first=0, H=H, FF=FF)
+    torch.cuda.synchronize()
+    assert torch.equal(ids, ids0) and torch.equal(w, w0) and torch.equal(out, want)
+    if E >= 8:
+        shard = tuple(t[2:E].contiguous() for t in tl)
+        o_sh, ids_sh, _ = m355.moe_nf4_forward_logits(x, lg, k, *shard, E_local=E - 2, e_first=2, H=H, FF=FF)
+        want_sh = m355.moe_nf4_forward(x, ids0, w0, *shard, E_local=E - 2, e_first=2, H=H, FF=FF)
+        torch.cuda.synchronize()
+        assert torch.equal(ids_sh, ids0) and torch.equal(o_sh, want_sh)
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("lens,window,use_sinks", [([1], 0, False), ([37], 0, False), ([200, 3, 65], 0, True),
                                                    ([130, 64], 48, True), ([300], 128, False), ([0, 5, 33], 0, False)])
