@@ -188,9 +188,9 @@ class GptOssDecodeLayer:
                               workspace=self.attn_ws, out=self.attn, sinks=w.get("sinks"), window=self.window)
         lib.linear_f16(self.attn.view(T, self.Hq * self.D), w["wo"], w.get("bo"), resid=self.resid, out=self.resid2)
         # the router rides in the launch of the norm in front of the MoE block (one workgroup per token has the normalised
-        # row at hand): measured against the router inside the experts' gate_up launch, which m355_moe_nf4_forward_routed
-        # offers for up to 8 tokens, the whole stack runs 1.623 against 1.637 ms per step at bs=1, and 2.795 against 2.851 at
-        # bs=32 where the router was a launch of its own
+        # row at hand).  Measured against the norm alone followed by m355_moe_nf4_forward_routed (logits as a launch of
+        # their own over every CU, top-k inside the gate_up launch): the whole stack runs 1.387 against 1.391 ms per step
+        # at bs=1 (one launch more there), and 2.795 against 2.851 at bs=32 where the router is a launch of its own
         lib.add_rmsnorm_router(self.resid2, None, w["ln2"], self.eps, w["router_w"], w.get("router_b"), self.k, out=self.h2,
                                ids=self.ids, w=self.wts)
         lib.moe_nf4_forward(self.h2, self.ids, self.wts, w["w13_q"], w["w13_absmax"], w["w2_q"], w["w2_absmax"],
