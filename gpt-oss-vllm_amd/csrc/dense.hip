@@ -8,6 +8,7 @@
 // and stay in registers for the whole kernel.  The A fragments of the next item are requested as soon as the current
 // item's are consumed (register ring), a row of W being read in whole 128-byte lines (four lanes x 32 bytes).
 #include "common.h"
+#include "norm_shared.h"
 
 namespace m355 {
 
@@ -210,11 +211,27 @@ struct RopeKvArgs {
     half_t *q_out, *kcache, *vcache;
 };
 
-template <int TN, int J>
+// NORM 1 / 2: x is the residual stream and the projection's input is its RMSNorm, formed here -- after delta has been
+// added (1), or the expert outputs that a forward called with M355_FLAG_SKIP_COMBINE left in its workspace (2), as
+// m355_add_rmsnorm / m355_moe_combine_add_rmsnorm do, by the same device code: every workgroup normalises the few rows
+// for itself into LDS while its first weights are on their way, and workgroup 0 writes the new residual stream.
+struct NormArgs {
+    const half_t *delta, *weight;
+    float eps;
+    half_t* resid_out;
+    const half_t* cy;
+    const int32_t* cinv;
+    const float* cw;
+    int k_top, fp16_mode;
+};
+
+template <int TN, int J, int NORM>
 __global__ __launch_bounds__(DENSE_THREADS) void qkv_rope_gemv_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
                                                                       const half_t* __restrict__ bias, int N, int K,
-                                                                      RopeKvArgs ra) {
+                                                                      RopeKvArgs ra, NormArgs na) {
+    extern __shared__ __attribute__((aligned(16))) half_t yrows[];   // NORM: [TN][K] normalised rows
     __shared__ float part[GEMV_ROWS][2][TN];
+    __shared__ float norm_part[TN][NORM_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half_d = ra.D / 2, n_pairs = N / 2;
@@ -230,16 +247,9 @@ __global__ __launch_bounds__(DENSE_THREADS) void qkv_rope_gemv_kernel(const half
         return head * ra.D + d + (lr & 1) * half_d;
     };
     u32x4_t xr[TN][J];
-#pragma unroll
-    for (int t = 0; t < TN; t++)
-#pragma unroll
-        for (int j = 0; j < J; j++) {
-            const int c = lane + 64 * j;
-            xr[t][j] = c < C ? reinterpret_cast<const u32x4_t*>(xh + (int64_t)t * K)[c] : u32x4_t{0u, 0u, 0u, 0u};
-        }
-    for (int pb = p0; pb < p1; pb += GEMV_ROWS / 2) {
-        const int pairs = min(GEMV_ROWS / 2, p1 - pb), rows = 2 * pairs;
-        u32x4_t a[GEMV_UNITS][J];
+    u32x4_t a[GEMV_UNITS][J];
+    auto request_rows = [&](int pb) {   // the weights of the batch of pairs that starts at pb
+        const int rows = 2 * min(GEMV_ROWS / 2, p1 - pb);
 #pragma unroll
         for (int u = 0; u < GEMV_UNITS; u++) {
             const int lr = (wv >> 1) + (DENSE_KPARTS / 2) * u;
@@ -252,6 +262,27 @@ __global__ __launch_bounds__(DENSE_THREADS) void qkv_rope_gemv_kernel(const half
                 }
             }
         }
+    };
+    if constexpr (NORM != 0) {
+        if (p0 < p1) request_rows(p0);
+#pragma unroll
+        for (int t = 0; t < TN; t++)
+            add_rmsnorm_row<NORM == 2 ? 1 : 0>(tid < NORM_THREADS, t, tid, x, na.delta, na.weight, na.eps, K,
+                                               blockIdx.x == 0 ? na.resid_out : nullptr, nullptr, na.cy, na.cinv, na.cw, na.k_top,
+                                               na.fp16_mode, norm_part[t], yrows + (size_t)t * K);
+        __syncthreads();
+        xh = yrows + kh * (K / 2);
+    }
+#pragma unroll
+    for (int t = 0; t < TN; t++)
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+            const int c = lane + 64 * j;
+            xr[t][j] = c < C ? reinterpret_cast<const u32x4_t*>(xh + (int64_t)t * K)[c] : u32x4_t{0u, 0u, 0u, 0u};
+        }
+    for (int pb = p0; pb < p1; pb += GEMV_ROWS / 2) {
+        const int pairs = min(GEMV_ROWS / 2, p1 - pb), rows = 2 * pairs;
+        if (NORM == 0 || pb != p0) request_rows(pb);
 #pragma unroll
         for (int u = 0; u < GEMV_UNITS; u++) {
             const int lr = (wv >> 1) + (DENSE_KPARTS / 2) * u;
@@ -299,19 +330,30 @@ __global__ __launch_bounds__(DENSE_THREADS) void qkv_rope_gemv_kernel(const half
     }
 }
 
-template <int TN>
-static int launch_qkv_rope(const half_t* x, const half_t* w, const half_t* bias, int N, int K, const RopeKvArgs& ra, int cus,
-                           hipStream_t st) {
+template <int TN, int NORM>
+static int launch_qkv_rope(const half_t* x, const half_t* w, const half_t* bias, int N, int K, const RopeKvArgs& ra,
+                           const NormArgs& na, int cus, hipStream_t st) {
     const int grid = N / 2 < cus ? N / 2 : cus;
     const int J = (K / 16 + 63) / 64;
+    const size_t lds = NORM ? (size_t)TN * K * 2 : 0;
     switch (J) {
-    case 1: qkv_rope_gemv_kernel<TN, 1><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, N, K, ra); break;
-    case 2: qkv_rope_gemv_kernel<TN, 2><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, N, K, ra); break;
-    case 3: qkv_rope_gemv_kernel<TN, 3><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, N, K, ra); break;
-    default: qkv_rope_gemv_kernel<TN, 4><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, N, K, ra); break;
+    case 1: qkv_rope_gemv_kernel<TN, 1, NORM><<<dim3(grid), dim3(DENSE_THREADS), lds, st>>>(x, w, bias, N, K, ra, na); break;
+    case 2: qkv_rope_gemv_kernel<TN, 2, NORM><<<dim3(grid), dim3(DENSE_THREADS), lds, st>>>(x, w, bias, N, K, ra, na); break;
+    case 3: qkv_rope_gemv_kernel<TN, 3, NORM><<<dim3(grid), dim3(DENSE_THREADS), lds, st>>>(x, w, bias, N, K, ra, na); break;
+    default: qkv_rope_gemv_kernel<TN, 4, NORM><<<dim3(grid), dim3(DENSE_THREADS), lds, st>>>(x, w, bias, N, K, ra, na); break;
     }
     M355_LAUNCH_CHECK("qkv_rope_gemv_kernel");
     return 0;
+}
+template <int NORM>
+static int launch_qkv_rope_t(int T, const half_t* x, const half_t* w, const half_t* bias, int N, int K, const RopeKvArgs& ra,
+                             const NormArgs& na, int cus, hipStream_t st) {
+    switch (T) {
+    case 1: return launch_qkv_rope<1, NORM>(x, w, bias, N, K, ra, na, cus, st);
+    case 2: return launch_qkv_rope<2, NORM>(x, w, bias, N, K, ra, na, cus, st);
+    case 3: return launch_qkv_rope<3, NORM>(x, w, bias, N, K, ra, na, cus, st);
+    default: return launch_qkv_rope<4, NORM>(x, w, bias, N, K, ra, na, cus, st);
+    }
 }
 
 template <int TN>
@@ -414,16 +456,61 @@ extern "C" int m355_qkv_rope_kv_write(const void* x_f16, int T, const void* wqkv
                                (half_t*)q_out_f16, (half_t*)kcache_f16, (half_t*)vcache_f16};
         const half_t *x = (const half_t*)x_f16, *w = (const half_t*)wqkv_f16, *b = (const half_t*)bqkv_f16;
         hipStream_t st = (hipStream_t)stream;
-        switch (T) {
-        case 1: return launch_qkv_rope<1>(x, w, b, N, K, ra, cus, st);
-        case 2: return launch_qkv_rope<2>(x, w, b, N, K, ra, cus, st);
-        case 3: return launch_qkv_rope<3>(x, w, b, N, K, ra, cus, st);
-        default: return launch_qkv_rope<4>(x, w, b, N, K, ra, cus, st);
-        }
+        return launch_qkv_rope_t<0>(T, x, w, b, N, K, ra, NormArgs{}, cus, st);
     }
     // more tokens: the two launches, through the caller's qkv buffer
     if (!qkv_scratch_f16) return fail(-1, "m355_qkv_rope_kv_write: more than %d tokens need the qkv scratch buffer", GEMV_MAX_T);
     if (int rc = m355_linear_f16(x_f16, T, wqkv_f16, bqkv_f16, N, K, nullptr, qkv_scratch_f16, stream)) return rc;
     return m355_rope_kv_write(qkv_scratch_f16, cos_f16, sin_f16, positions, slots, T, Hq, Hkv, D, block_size, max_pos, q_out_f16,
                               kcache_f16, vcache_f16, stream);
+}
+
+extern "C" int m355_norm_qkv_rope_kv_write(const void* x_f16, const void* delta_f16, const void* moe_workspace, size_t ws_bytes,
+                                           int k, int FF, int E_local, const float* combine_w, int flags,
+                                           const void* ln_weight_f16, float eps, int T, int K, const void* wqkv_f16,
+                                           const void* bqkv_f16, const void* cos_f16, const void* sin_f16,
+                                           const int32_t* positions, const int64_t* slots, int Hq, int Hkv, int D,
+                                           int block_size, int max_pos, void* resid_out_f16, void* h_scratch_f16,
+                                           void* qkv_scratch_f16, void* q_out_f16, void* kcache_f16, void* vcache_f16,
+                                           m355_stream_t stream) {
+    if (T == 0) return 0;
+    if (!x_f16 || !ln_weight_f16 || !wqkv_f16 || !cos_f16 || !sin_f16 || !positions || !slots || !q_out_f16 || !kcache_f16 ||
+        !vcache_f16 || (moe_workspace && !combine_w))
+        return fail(-1, "m355_norm_qkv_rope_kv_write: null pointer");
+    if (moe_workspace && delta_f16) return fail(-2, "m355_norm_qkv_rope_kv_write: delta and a pending combine exclude each other");
+    if (T < 0 || Hq <= 0 || Hkv <= 0 || D <= 0 || (D % 16) || block_size <= 0 || max_pos <= 0 || K <= 0 || (K % 64) ||
+        K > 8 * NORM_THREADS * 4 || (moe_workspace && (k <= 0 || k > 32 || FF <= 0 || E_local <= 0)))
+        return fail(-2, "m355_norm_qkv_rope_kv_write: unsupported shape T=%d Hq=%d Hkv=%d D=%d K=%d block_size=%d k=%d", T, Hq, Hkv, D,
+                    K, block_size, k);
+    const int N = (Hq + 2 * Hkv) * D;
+    if (T <= GEMV_MAX_T && K <= 64 * 64) {
+        if (!aligned(x_f16, 16) || !aligned(wqkv_f16, 16) || !aligned(ln_weight_f16, 16) || (delta_f16 && !aligned(delta_f16, 16)) ||
+            (resid_out_f16 && !aligned(resid_out_f16, 16)) || (moe_workspace && !aligned(moe_workspace, 256)))
+            return fail(-3, "m355_norm_qkv_rope_kv_write: x, delta, the norm weight, wqkv and resid_out must be 16-byte aligned, the workspace 256-byte");
+        int dev = 0, cus = 0;
+        if (int rc = hip_status(hipGetDevice(&dev), "hipGetDevice")) return rc;
+        if (int rc = hip_status(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute")) return rc;
+        if (cus <= 0) cus = 256;
+        const RopeKvArgs ra = {(const half_t*)cos_f16, (const half_t*)sin_f16, positions, slots, Hq, Hkv, D, block_size, max_pos,
+                               (half_t*)q_out_f16, (half_t*)kcache_f16, (half_t*)vcache_f16};
+        NormArgs na = {(const half_t*)delta_f16, (const half_t*)ln_weight_f16, eps, (half_t*)resid_out_f16, nullptr, nullptr, nullptr, 0, 0};
+        const half_t *x = (const half_t*)x_f16, *w = (const half_t*)wqkv_f16, *b = (const half_t*)bqkv_f16;
+        hipStream_t st = (hipStream_t)stream;
+        if (moe_workspace) {
+            const MoeWorkspace ws = carve_workspace(const_cast<void*>(moe_workspace), T, k, K, FF, E_local);
+            if (ws_bytes < ws.bytes)
+                return fail(-6, "m355_norm_qkv_rope_kv_write: the workspace of that forward has %zu bytes, %zu given", ws.bytes, ws_bytes);
+            na.cy = ws.y; na.cinv = ws.inv; na.cw = combine_w; na.k_top = k; na.fp16_mode = (flags & M355_FLAG_FP16_COMBINE) ? 1 : 0;
+            return launch_qkv_rope_t<2>(T, x, w, b, N, K, ra, na, cus, st);
+        }
+        return launch_qkv_rope_t<1>(T, x, w, b, N, K, ra, na, cus, st);
+    }
+    // more tokens: the norm as its own launch into the caller's buffer, then the projection
+    if (!h_scratch_f16) return fail(-1, "m355_norm_qkv_rope_kv_write: more than %d tokens need the buffer for the normalised rows", GEMV_MAX_T);
+    if (int rc = moe_workspace ? m355_moe_combine_add_rmsnorm(moe_workspace, ws_bytes, T, k, FF, E_local, combine_w, flags, x_f16,
+                                                              ln_weight_f16, eps, K, resid_out_f16, h_scratch_f16, stream)
+                               : m355_add_rmsnorm(x_f16, delta_f16, ln_weight_f16, eps, T, K, resid_out_f16, h_scratch_f16, stream))
+        return rc;
+    return m355_qkv_rope_kv_write(h_scratch_f16, T, wqkv_f16, bqkv_f16, K, cos_f16, sin_f16, positions, slots, Hq, Hkv, D, block_size,
+                                  max_pos, qkv_scratch_f16, q_out_f16, kcache_f16, vcache_f16, stream);
 }

@@ -173,14 +173,12 @@ class GptOssDecodeLayer:
         T = resid_in.shape[0]
         if T != self.T:
             raise ValueError(f"built for {self.T} tokens per step, got {T}")
-        if isinstance(delta, PendingCombine):
-            lib.moe_combine_add_rmsnorm(delta.workspace, delta.w, FF=delta.FF, E_local=delta.E, flags=delta.flags, x=resid_in,
-                                        weight=w["ln1"], eps=self.eps, resid_out=self.resid, out=self.h1)
-        else:
-            lib.add_rmsnorm(resid_in, delta, w["ln1"], self.eps, resid_out=self.resid, out=self.h1)
-        # projection, rotary embedding and cache write: one launch up to 4 tokens, the two launches beyond (same bits)
-        lib.qkv_rope_kv_write(self.h1, w["wqkv"], w.get("bqkv"), cos, sin, positions, slots, kcache, vcache, Hq=self.Hq,
-                              Hkv=self.Hkv, D=self.D, q_out=self.q, qkv_scratch=self.qkv)
+        # residual add (or the previous layer's combine), input norm, q/k/v projection, rotary embedding and cache write:
+        # one launch up to 4 tokens, the norm's launch and the projection's one or two beyond (same bits)
+        pending = (delta.workspace, delta.w, delta.FF, delta.E, delta.flags) if isinstance(delta, PendingCombine) else delta
+        lib.norm_qkv_rope_kv_write(resid_in, pending, w["ln1"], self.eps, w["wqkv"], w.get("bqkv"), cos, sin, positions, slots,
+                                   kcache, vcache, Hq=self.Hq, Hkv=self.Hkv, D=self.D, resid_out=self.resid, q_out=self.q,
+                                   h_scratch=self.h1, qkv_scratch=self.qkv)
         need = lib.paged_attn_workspace_bytes(T, self.Hq, self.D, max_ctx)
         if need and (self.attn_ws is None or self.attn_ws.numel() < need):
             self.attn_ws = torch.empty(need, dtype=torch.uint8, device=self.q.device)

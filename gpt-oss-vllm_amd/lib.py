@@ -31,7 +31,7 @@ EXPORTS = (
     "m355_repack_nf4_ex", "m355_moe_nf4_forward_ex", "m355_moe_nf4_forward_q8", "m355_repack_absmax_u8",
     "m355_moe_nf4_forward_routed", "m355_attn_prefill", "m355_moe_combine_add_rmsnorm", "m355_init",
     "m355_moe_nf4_forward_static", "m355_router_topk_ep_pack", "m355_moe_nf4_forward_ep_rows", "m355_ep_reduce_add_rmsnorm",
-    "m355_qkv_rope_kv_write", "m355_moe_nf4_forward_logits",
+    "m355_qkv_rope_kv_write", "m355_moe_nf4_forward_logits", "m355_norm_qkv_rope_kv_write",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -113,6 +113,9 @@ def load() -> ctypes.CDLL:
     L.m355_rope_kv_write.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]
     L.m355_qkv_rope_kv_write.argtypes = [vp, i32, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.m355_qkv_rope_kv_write.restype = i32
+    L.m355_norm_qkv_rope_kv_write.argtypes = [vp, vp, vp, sz, i32, i32, i32, vp, i32, vp, f32, i32, i32, vp, vp, vp, vp, vp, vp,
+                                              i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.m355_norm_qkv_rope_kv_write.restype = i32
     for fn in ("m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce", "m355_nf4_dequant", "m355_repack_nf4", "m355_router_topk", "m355_topk_softmax",
                "m355_moe_nf4_forward", "m355_paged_attn_decode", "m355_add_rmsnorm", "m355_rope_kv_write"):
         getattr(L, fn).restype = i32
@@ -647,6 +650,50 @@ def qkv_rope_kv_write(x: torch.Tensor, wqkv: torch.Tensor, bqkv: Optional[torch.
         _dev(slots, torch.int64, "slots"), Hq, Hkv, D, kcache.shape[1], cos.shape[0],
         None if qkv_scratch is None else _dev(qkv_scratch, torch.float16, "qkv_scratch"), _dev(q_out, torch.float16, "q_out"),
         _dev(kcache, torch.float16, "kcache"), _dev(vcache, torch.float16, "vcache"), _stream()), "m355_qkv_rope_kv_write")
+    return q_out
+
+
+def norm_qkv_rope_kv_write(x: torch.Tensor, delta, ln_weight: torch.Tensor, eps: float, wqkv: torch.Tensor,
+                           bqkv: Optional[torch.Tensor], cos: torch.Tensor, sin: torch.Tensor, positions: torch.Tensor,
+                           slots: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, *, Hq: int, Hkv: int, D: int,
+                           resid_out: Optional[torch.Tensor] = None, q_out: Optional[torch.Tensor] = None,
+                           h_scratch: Optional[torch.Tensor] = None, qkv_scratch: Optional[torch.Tensor] = None):
+    """add_rmsnorm(x, delta) followed by qkv_rope_kv_write on the normalised rows, in one call (one launch up to 4
+    tokens).  delta: None, a tensor [T][K], or (moe_workspace, w, FF, E_local, flags) for the expert outputs a MoE forward
+    left uncombined (FLAG_SKIP_COMBINE), as moe_combine_add_rmsnorm takes them.  resid_out receives x + delta.
+    m355_norm_qkv_rope_kv_write."""
+    T, K = x.shape
+    N = (Hq + 2 * Hkv) * D
+    if wqkv.shape != (N, K):
+        raise ValueError(f"wqkv is {tuple(wqkv.shape)}, expected {(N, K)}")
+    if cos.shape != sin.shape or cos.shape[1] != D // 2:
+        raise ValueError("cos/sin must be [max_pos][D/2]")
+    if kcache.shape != vcache.shape or kcache.shape[2] != Hkv or kcache.shape[3] != D:
+        raise ValueError("caches must be [blocks][block_size][Hkv][D]")
+    if q_out is None:
+        q_out = torch.empty((T, Hq, D), dtype=torch.float16, device=x.device)
+    if T > 4:
+        if h_scratch is None:
+            h_scratch = torch.empty((T, K), dtype=torch.float16, device=x.device)
+        if qkv_scratch is None:
+            qkv_scratch = torch.empty((T, N), dtype=torch.float16, device=x.device)
+    ws_ptr, ws_bytes, k, FF, E_local, cw, flags, delta_ptr = None, 0, 0, 0, 0, None, 0, None
+    if isinstance(delta, tuple):
+        ws_t, w_t, FF, E_local, flags = delta
+        if w_t.shape[0] != T:
+            raise ValueError(f"w has {w_t.shape[0]} rows, x has {T}")
+        ws_ptr, ws_bytes, k, cw = _dev(ws_t, torch.uint8, "moe_workspace"), ws_t.numel(), w_t.shape[1], _dev(w_t, torch.float32, "w")
+    elif delta is not None:
+        delta_ptr = _dev(delta, torch.float16, "delta")
+    _check(load().m355_norm_qkv_rope_kv_write(
+        _dev(x, torch.float16, "x"), delta_ptr, ws_ptr, ws_bytes, k, int(FF), int(E_local), cw, int(flags),
+        _dev(ln_weight, torch.float16, "ln_weight"), float(eps), T, K, _dev(wqkv, torch.float16, "wqkv"),
+        None if bqkv is None else _dev(bqkv, torch.float16, "bqkv"), _dev(cos, torch.float16, "cos"), _dev(sin, torch.float16, "sin"),
+        _dev(positions, torch.int32, "positions"), _dev(slots, torch.int64, "slots"), Hq, Hkv, D, kcache.shape[1], cos.shape[0],
+        None if resid_out is None else _dev(resid_out, torch.float16, "resid_out"),
+        None if h_scratch is None else _dev(h_scratch, torch.float16, "h_scratch"),
+        None if qkv_scratch is None else _dev(qkv_scratch, torch.float16, "qkv_scratch"), _dev(q_out, torch.float16, "q_out"),
+        _dev(kcache, torch.float16, "kcache"), _dev(vcache, torch.float16, "vcache"), _stream()), "m355_norm_qkv_rope_kv_write")
     return q_out
 
 

@@ -332,6 +332,25 @@ M355_API int m355_qkv_rope_kv_write(const void* x_f16, int T, const void* wqkv_f
                                     const void* cos_f16, const void* sin_f16, const int32_t* positions, const int64_t* slots,
                                     int Hq, int Hkv, int D, int block_size, int max_pos, void* qkv_scratch_f16,
                                     void* q_out_f16, void* kcache_f16, void* vcache_f16, m355_stream_t stream);
+/*
+ * m355_norm_qkv_rope_kv_write: the residual add + input RMSNorm of a decoder layer in front of m355_qkv_rope_kv_write, in
+ *   the same call: GptOssDecoderLayer.forward from `residual + hidden_states` of the layer before through
+ *   input_layernorm to the attention's q/k/v, rotary embedding and cache update (modeling_gpt_oss.py, as cited above).
+ *   x [T][K]: the residual stream; delta [T][K] (or NULL) is added first -- or, with moe_workspace non-NULL, the expert
+ *   outputs that a forward of the same T, k, K (= H), FF, E_local called with M355_FLAG_SKIP_COMBINE left there
+ *   (combine_w: its routing weights, flags: its M355_FLAG_FP16_COMBINE), as m355_moe_combine_add_rmsnorm forms them.
+ *   resid_out [T][K] (or NULL) receives the sum.  Up to 4 tokens it is ONE launch: every workgroup of the projection
+ *   normalises the rows for itself while its first weights are on their way (h_scratch, qkv_scratch may be NULL);
+ *   beyond, the norm's launch into h_scratch [T][K] followed by m355_qkv_rope_kv_write.  The same bits either way.
+ */
+M355_API int m355_norm_qkv_rope_kv_write(const void* x_f16, const void* delta_f16, const void* moe_workspace, size_t ws_bytes,
+                                         int k, int FF, int E_local, const float* combine_w, int flags,
+                                         const void* ln_weight_f16, float eps, int T, int K, const void* wqkv_f16,
+                                         const void* bqkv_f16, const void* cos_f16, const void* sin_f16,
+                                         const int32_t* positions, const int64_t* slots, int Hq, int Hkv, int D,
+                                         int block_size, int max_pos, void* resid_out_f16, void* h_scratch_f16,
+                                         void* qkv_scratch_f16, void* q_out_f16, void* kcache_f16, void* vcache_f16,
+                                         m355_stream_t stream);
 
 #ifdef __cplusplus
 }

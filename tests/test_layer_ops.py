@@ -177,6 +177,66 @@ def test_gpu_qkv_rope_kv_write_equals_the_two_launches(T, Hq, Hkv, D, K, bias):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,Hq,Hkv,D,K,bias,mode", [(1, 64, 8, 64, 2880, True, "delta"), (1, 64, 8, 64, 2880, False, "pending"),
+                                                    (4, 64, 8, 64, 2880, True, "pending"), (3, 8, 2, 32, 256, False, "none"),
+                                                    (2, 4, 4, 64, 4096, True, "delta"), (6, 8, 2, 32, 256, True, "pending"),
+                                                    (5, 8, 2, 32, 320, False, "delta")])
+def test_gpu_norm_qkv_rope_kv_write_equals_the_launches(T, Hq, Hkv, D, K, bias, mode):
+    """m355_norm_qkv_rope_kv_write (one launch up to 4 tokens) against the norm's launch (m355_add_rmsnorm, or
+    m355_moe_combine_add_rmsnorm on the expert outputs a forward left uncombined) followed by m355_qkv_rope_kv_write: the new
+    residual stream, q and every word of both caches, bit for bit."""
+    from gpt_oss_vllm_amd import lib
+    from test_gpu_parity import tiled_layer
+    cuda = torch.device("cuda:0")
+    sd = oracle_ref.stream_seed(730, T, Hq, K)
+    N, block_size, nblocks, max_pos = (Hq + 2 * Hkv) * D, 16, 5, 40
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    x = dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 1), (T, K)))
+    w = dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 2), (N, K), 0.03))
+    b = dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 3), (N,), 0.2)) if bias else None
+    cos = dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 4), (max_pos, D // 2)))
+    sin = dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 5), (max_pos, D // 2)))
+    ln = dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 6), (K,)))
+    positions = torch.tensor([(7 * t + 3) % max_pos for t in range(T)], dtype=torch.int32, device=cuda)
+    slots = torch.tensor([(11 * t + 5) % (nblocks * block_size) if t != 1 else -1 for t in range(T)], dtype=torch.int64, device=cuda)
+    delta = None
+    if mode == "delta":
+        delta = dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 7), (T, K)))
+    elif mode == "pending":      # a MoE forward of the same tokens that stopped before its combine step
+        E, k, FF = 8, 2, 192
+        layer = oracle_ref.synth_layer(oracle_ref.stream_seed(sd, 8), E, K, FF)
+        tl = tiled_layer(lib, layer, E, K, FF, cuda)
+        lg = oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 9), (T, E), 1.5)
+        ids, wts, _ = oracle_ref.router_topk(lg, np.eye(E, dtype=np.float16), None, k)
+        ws = torch.empty(max(256, lib.moe_workspace_bytes(T, k, K, FF, E)), dtype=torch.uint8, device=cuda)
+        xe = dev(oracle_ref.normal_f16(oracle_ref.stream_seed(sd, 10), (T, K)))
+        wts_d = dev(wts)
+        lib.moe_nf4_forward(xe, dev(ids), wts_d, *tl, E_local=E, e_first=0, H=K, FF=FF, workspace=ws,
+                            flags=lib.FLAG_FP16_COMBINE | lib.FLAG_SKIP_COMBINE)
+        delta = (ws, wts_d, FF, E, lib.FLAG_FP16_COMBINE)
+    outs = []
+    for fused in (False, True):
+        kc = torch.full((nblocks, block_size, Hkv, D), 7.0, dtype=torch.float16, device=cuda)
+        vc = torch.full((nblocks, block_size, Hkv, D), 7.0, dtype=torch.float16, device=cuda)
+        resid = torch.full((T, K), float("nan"), dtype=torch.float16, device=cuda)
+        if fused:
+            q = lib.norm_qkv_rope_kv_write(x, delta, ln, 1e-5, w, b, cos, sin, positions, slots, kc, vc, Hq=Hq, Hkv=Hkv, D=D,
+                                           resid_out=resid)
+        else:
+            if mode == "pending":
+                h = lib.moe_combine_add_rmsnorm(delta[0], delta[1], FF=delta[2], E_local=delta[3], flags=delta[4], x=x, weight=ln,
+                                                eps=1e-5, resid_out=resid)
+            else:
+                h = lib.add_rmsnorm(x, delta, ln, 1e-5, resid_out=resid)
+            q = lib.qkv_rope_kv_write(h, w, b, cos, sin, positions, slots, kc, vc, Hq=Hq, Hkv=Hkv, D=D)
+        outs.append((q, kc, vc, resid))
+    torch.cuda.synchronize()
+    for a, c in zip(outs[0], outs[1]):
+        assert torch.equal(a.view(torch.int16), c.view(torch.int16))
+    assert not torch.isnan(outs[1][3]).any() and not (outs[1][1] == 7.0).all()
+
+
+@pytest.mark.gpu
 def test_gpu_linear_f16_prompt_size():
     """8192 tokens through the q/k/v projection shape (256-token tiles): sampled tokens against an fp32 matmul, and
     the result is the same whatever else shares the launch (a token's row alone through the small-batch kernel)."""
