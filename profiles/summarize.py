@@ -92,10 +92,13 @@ with open(f"profiles/{tag}_summary.md", "w") as out:
             if isinstance(r, dict) and "avg_us" in r and gu:
                 v = max(gu, key=len)
                 avg = sum(v) / len(v) / 1e3
+                b2b = r.get("back_to_back", {}).get("avg_us")
                 out.write(f"\nbench.py's own figure for the gate_up launch as the step runs it, from a run of the same command without the "
-                          f"profiler (HIP events around 24 back-to-back launches in one graph, so it includes the gaps between launches): "
-                          f"{r['avg_us']:.2f} us, frac {r['frac']:.3f}; the trace row above (kernel time alone): {avg:.2f} us over {len(v)} "
-                          f"launches ({(r['avg_us'] / avg - 1) * 100:+.1f} %).  ms_per_step of that run: {line['ms_per_step']:.3f}.\n")
+                          f"profiler (`roofline.avg_us`: mean over HIP event pairs around single launches): "
+                          f"{r['avg_us']:.2f} us, frac {r['frac']:.3f}; the trace row above: {avg:.2f} us over {len(v)} "
+                          f"launches ({(r['avg_us'] / avg - 1) * 100:+.1f} %)."
+                          + (f"  24 launches back to back in one graph (launch + gap to the next): {b2b:.2f} us." if b2b else "")
+                          + f"  ms_per_step of that run: {line['ms_per_step']:.3f}.\n")
         out.write("\n")
     for _, d, _ in LEGS:
         if d in lines:
