@@ -20,6 +20,8 @@
 // Dequantisation: a byte holds two codes; a 256-entry table of packed half2 (code[lo], code[hi]) is
 // replicated 32x in LDS (entry address = (byte*32 + lane%32)*4) so a wave's lookups never collide on a bank.
 // The code values are fp16-rounded NF4 entries; scales stay fp32.
+#include <hip/hip_ext.h>
+
 #include "moe_shared.h"
 #include "router_shared.h"
 
@@ -1156,6 +1158,22 @@ static bool can_route_inline(int P, int E_local, int K) {
     return K / 64 <= MOE_KPARTS * MOE_CHUNK && P <= INLINE_MAX_P && E_local <= INLINE_MAX_E;
 }
 
+// Measuring aid: after m355_time_next_launch() the next streaming-kernel launch made from this thread carries start / stop
+// events of its own (hipExtLaunchKernelGGL), which bracket the kernel alone -- the duration a kernel trace reports, with
+// neither the gap to a neighbouring launch nor the cost of event markers around it.
+static thread_local hipEvent_t tl_time_start = nullptr, tl_time_stop = nullptr;
+static thread_local bool tl_time_armed = false, tl_time_taken = false;
+template <typename... KArgs, typename... Args>
+static void launch_stream_kernel(void (*kern)(KArgs...), dim3 grid, dim3 block, int lds, hipStream_t st, Args... args) {
+    if (tl_time_armed) {
+        tl_time_armed = false;
+        tl_time_taken = true;
+        hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)lds, st, tl_time_start, tl_time_stop, 0, static_cast<KArgs>(args)...);
+    } else {
+        kern<<<grid, block, lds, st>>>(static_cast<KArgs>(args)...);
+    }
+}
+
 // W [R][K] per expert.  K <= 48 blocks: streaming kernel, one or two workgroups per CU; else the general kernel.
 // `rio` non-null (gate_up only): the kernel buckets the pairs itself and leaves the lists in the workspace.
 template <int MODE, int INLINE>
@@ -1173,7 +1191,7 @@ static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, c
                 const int lds = stream_lds_bytes(1, 0, WIDE_KP, 2);
                 const int items1 = max_tiles * NP;
                 const int grid = items1 < cus ? items1 : cus;
-                moe_gemm_stream_kernel<MODE, 1, 0, WIDE_KP, 2><<<dim3(grid), dim3(WIDE_KP * 64), lds, st>>>(
+                launch_stream_kernel(moe_gemm_stream_kernel<MODE, 1, 0, WIDE_KP, 2>, dim3(grid), dim3(WIDE_KP * 64), lds, st,
                     xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio, sp, wam8, wtab, cio);
                 M355_LAUNCH_CHECK("moe_gemm_stream_kernel");
                 return 0;
@@ -1182,14 +1200,14 @@ static int launch_gemm(const half_t* xin, const uint8_t* wq, const float* wam, c
         if (2 * items2 >= cus) {   // 8-wave workgroups unless even those would leave most CUs idle
             const int lds = stream_lds_bytes(2, INLINE);
             const int grid = items2 < cus ? items2 : cus;
-            moe_gemm_stream_kernel<MODE, 2, INLINE><<<dim3(grid), dim3(512), lds, st>>>(
+            launch_stream_kernel(moe_gemm_stream_kernel<MODE, 2, INLINE>, dim3(grid), dim3(512), lds, st,
                 xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio, sp, wam8, wtab, cio);
         } else {
             const int lds = stream_lds_bytes(1, INLINE);
             const int per_cu = (2 * lds <= 160 * 1024) ? 2 : 1;
             const int items1 = max_tiles * NP;
             const int grid = items1 < per_cu * cus ? items1 : per_cu * cus;
-            moe_gemm_stream_kernel<MODE, 1, INLINE><<<dim3(grid), dim3(256), lds, st>>>(
+            launch_stream_kernel(moe_gemm_stream_kernel<MODE, 1, INLINE>, dim3(grid), dim3(256), lds, st,
                 xin, wq, wam, ws.n_tiles, ws.tile_expert, ws.tile_m0, ws.offsets, ws.sorted, K, R, k_top, mt_rows, outp, table_len, rio, sp, wam8, wtab, cio);
         }
         M355_LAUNCH_CHECK("moe_gemm_stream_kernel");
@@ -1217,6 +1235,26 @@ extern "C" __attribute__((visibility("default"))) int m355_dbg_read(void* host, 
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(m355_dbg), bytes < sizeof(m355_dbg) ? bytes : sizeof(m355_dbg));
 }
 #endif
+
+extern "C" int m355_time_next_launch(void) {
+    if (!tl_time_start) {
+        if (int rc = hip_status(hipEventCreate(&tl_time_start), "hipEventCreate")) return rc;
+        if (int rc = hip_status(hipEventCreate(&tl_time_stop), "hipEventCreate")) return rc;
+    }
+    tl_time_armed = true;
+    tl_time_taken = false;
+    return 0;
+}
+
+extern "C" int m355_timed_launch_us(float* us) {
+    if (!us) return fail(-1, "m355_timed_launch_us: null pointer");
+    if (!tl_time_taken) return fail(-2, "m355_timed_launch_us: no streaming-kernel launch since m355_time_next_launch");
+    if (int rc = hip_status(hipEventSynchronize(tl_time_stop), "hipEventSynchronize")) return rc;
+    float ms = 0.f;
+    if (int rc = hip_status(hipEventElapsedTime(&ms, tl_time_start, tl_time_stop), "hipEventElapsedTime")) return rc;
+    *us = ms * 1e3f;
+    return 0;
+}
 
 extern "C" size_t m355_moe_workspace_bytes(int T, int k, int H, int FF, int E_local) {
     if (T < 0 || k <= 0 || H <= 0 || FF <= 0 || E_local <= 0) return 0;

@@ -32,6 +32,7 @@ EXPORTS = (
     "m355_moe_nf4_forward_routed", "m355_attn_prefill", "m355_moe_combine_add_rmsnorm", "m355_init",
     "m355_moe_nf4_forward_static", "m355_router_topk_ep_pack", "m355_moe_nf4_forward_ep_rows", "m355_ep_reduce_add_rmsnorm",
     "m355_qkv_rope_kv_write", "m355_moe_nf4_forward_logits", "m355_norm_qkv_rope_kv_write",
+    "m355_time_next_launch", "m355_timed_launch_us",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -116,6 +117,10 @@ def load() -> ctypes.CDLL:
     L.m355_norm_qkv_rope_kv_write.argtypes = [vp, vp, vp, sz, i32, i32, i32, vp, i32, vp, f32, i32, i32, vp, vp, vp, vp, vp, vp,
                                               i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.m355_norm_qkv_rope_kv_write.restype = i32
+    L.m355_time_next_launch.argtypes = []
+    L.m355_time_next_launch.restype = i32
+    L.m355_timed_launch_us.argtypes = [ctypes.POINTER(ctypes.c_float)]
+    L.m355_timed_launch_us.restype = i32
     for fn in ("m355_ep_pack", "m355_ep_unpack", "m355_ep_reduce", "m355_nf4_dequant", "m355_repack_nf4", "m355_router_topk", "m355_topk_softmax",
                "m355_moe_nf4_forward", "m355_paged_attn_decode", "m355_add_rmsnorm", "m355_rope_kv_write"):
         getattr(L, fn).restype = i32
@@ -386,6 +391,18 @@ def moe_nf4_forward_routed(x, wr, br, k: int, w13_q, w13_absmax, w2_q, w2_absmax
         float(alpha), float(limit), _dev(workspace, torch.uint8, "workspace"), workspace.numel(),
         _dev(out, torch.float16, "out"), _stream()), "m355_moe_nf4_forward_routed")
     return out, ids, w
+
+
+def time_next_launch():
+    """Arm this thread: the next streaming MoE GEMM launch is bracketed by events of its own.  m355_time_next_launch."""
+    _check(load().m355_time_next_launch(), "m355_time_next_launch")
+
+
+def timed_launch_us() -> float:
+    """Duration in microseconds of the launch armed by time_next_launch() (waits for it).  m355_timed_launch_us."""
+    us = ctypes.c_float(0.0)
+    _check(load().m355_timed_launch_us(ctypes.byref(us)), "m355_timed_launch_us")
+    return float(us.value)
 
 
 def moe_nf4_forward_logits(x, logits, k: int, w13_q, w13_absmax, w2_q, w2_absmax, *, E_local: int, e_first: int, H: int,

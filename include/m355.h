@@ -214,6 +214,13 @@ M355_API int m355_attn_prefill(const void* q_f16, const void* k_f16, const void*
 M355_API int m355_repack_absmax_u8(const uint8_t* absmax_u8, int rows, int cols, int row_order, uint8_t* absmax_tiled,
                                    m355_stream_t stream);
 M355_API size_t m355_moe_workspace_bytes(int T, int k, int H, int FF, int E_local);
+/* Measuring aid, no counterpart in the reference: m355_time_next_launch() arms the calling thread so that the next launch
+ * of the streaming MoE GEMM kernel it makes (the gate_up or the down stage of a small-batch m355_moe_nf4_forward*, not under
+ * graph capture) carries start / stop events of its own; m355_timed_launch_us() waits for that launch and returns the
+ * kernel's own duration in microseconds -- what a kernel trace reports for it, without the gap to neighbouring launches
+ * and without the cost of event markers around the call.  The first call on a thread creates the two events. */
+M355_API int m355_time_next_launch(void);
+M355_API int m355_timed_launch_us(float* us);
 
 /*
  * Decode attention over a paged KV cache: one query token per sequence, grouped-query heads, scores in

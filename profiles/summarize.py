@@ -14,7 +14,7 @@ src = f"gpurun_out/prof_{tag}"
 LEGS = [
     ("hot path bs=32", "hot32", "`bench.py --steps 10 --warmup 3 --legs roofline`: the headline step (attention, router, gate_up, down, combine) "
                                 "and the roofline leg's launches of the same gate_up / down kernels on the same inputs"),
-    ("hot path bs=1", "hot1", "the same with `--batch-per-gpu 1` (gate_up computes the router, the down launch combines)"),
+    ("hot path bs=1", "hot1", "the same with `--batch-per-gpu 1` (router_logits in front, gate_up picks the top-k, the down launch combines)"),
     ("prefill 8192 tokens", "prefill", "`--legs prefill`: prompt attention, tiled router, routing, tile kernel, combine (+ a few bs=32 headline steps)"),
     ("whole decoder stack", "full", "`--legs full`: 24 whole decoder layers at bs=32 and bs=1 (+ a few bs=32 headline steps)"),
     ("dequant / rank of 8", "side", "`--legs dequant,rank8`: the standalone dequantiser and the kernels of one rank of an 8-way shard (+ a few bs=32 headline steps)"),
@@ -94,7 +94,7 @@ with open(f"profiles/{tag}_summary.md", "w") as out:
                 avg = sum(v) / len(v) / 1e3
                 b2b = r.get("back_to_back", {}).get("avg_us")
                 out.write(f"\nbench.py's own figure for the gate_up launch as the step runs it, from a run of the same command without the "
-                          f"profiler (`roofline.avg_us`: mean over HIP event pairs around single launches): "
+                          f"profiler (`roofline.avg_us`: the kernel's own duration from start / stop events carried by each launch): "
                           f"{r['avg_us']:.2f} us, frac {r['frac']:.3f}; the trace row above: {avg:.2f} us over {len(v)} "
                           f"launches ({(r['avg_us'] / avg - 1) * 100:+.1f} %)."
                           + (f"  24 launches back to back in one graph (launch + gap to the next): {b2b:.2f} us." if b2b else "")
