@@ -594,7 +594,8 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
     unsigned char* red = smem + LUTP_BYTES;
     InlineTables* rt = reinterpret_cast<InlineTables*>(red + RED_ALL);
     static_assert(INLINE != 2 || INLINE_MAX_P * 8 + PAIRS * KP * SPLIT_ROUTER_MAX_E * 4 <= RED_ALL, "picks and a row of logits per wave");
-    int te_lane = 0;
+    int te_lane = 0, tm_lane = 0, of_lane = 0;
+    const int off_len = min(64, rio.E_local + 1);
     if constexpr (INLINE) {
         // the ids are requested first; the code table is built later, while the first weights are on their way
         int my_e = -1;
@@ -608,6 +609,57 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
             int32_t* il = reinterpret_cast<int32_t*>(wl + rio.P);
             const int wv_ = (int)threadIdx.x >> 6, ln_ = (int)threadIdx.x & 63;
             constexpr int NW = PAIRS * KP;
+            if (Tn == 1 && rio.r_E <= 64) {
+                // A single token (the whole batch of single-sequence decode): every wave picks AND buckets for itself, from
+                // registers, and leaves the same tables as inline_route() would -- an expert holds at most one pair, so a
+                // pair's place is the number of picked local experts with a smaller id.  All waves write the same values to
+                // the same LDS words and each reads only behind its own writes: no barrier in front of the first load.
+                const float mine = ln_ < rio.r_E ? (float)rio.r_logits[ln_] : 0.f;
+                topk_softmax_wave64(mine, rio.r_E, rio.r_k, il, wl);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const bool pair = ln_ < rio.r_k;
+                const int id_j = pair ? il[ln_] : 0;
+                const int e_j = id_j - rio.e_first;
+                const bool local = pair && e_j >= 0 && e_j < rio.E_local;
+                int pos = 0, off[(INLINE_MAX_E + 1 + 63) / 64];
+#pragma unroll
+                for (int c = 0; c < (INLINE_MAX_E + 1 + 63) / 64; c++) off[c] = 0;
+                for (int i = 0; i < rio.r_k; i++) {
+                    const int e_i = __builtin_amdgcn_readlane(e_j, i);
+                    const bool local_i = __builtin_amdgcn_readlane((int)local, i) != 0;
+                    pos += (local_i && e_i < e_j) ? 1 : 0;
+#pragma unroll
+                    for (int c = 0; c < (INLINE_MAX_E + 1 + 63) / 64; c++) off[c] += (local_i && e_i < ln_ + 64 * c) ? 1 : 0;
+                }
+                const int n_local = __builtin_popcountll(__ballot(local));
+                const bool scribe = blockIdx.x == 0 && wv_ == 0;
+                if (local) {
+                    rt->tile_e[pos] = e_j;
+                    rt->tile_m0[pos] = 0;
+                    rt->tok[pos] = ln_;
+                    if (scribe) { rio.tile_expert[pos] = e_j; rio.tile_m0[pos] = 0; rio.sorted[pos] = ln_; rio.active[pos] = e_j; }
+                }
+#pragma unroll
+                for (int c = 0; c < (INLINE_MAX_E + 1 + 63) / 64; c++) {
+                    const int e = ln_ + 64 * c;
+                    if (e <= rio.E_local) {
+                        rt->off[e] = off[c];
+                        if (scribe) rio.offsets[e] = off[c];
+                    }
+                }
+                if (ln_ == 0) {
+                    rt->nt = n_local;
+                    if (scribe) { *rio.n_active = n_local; *rio.n_tiles = n_local; }
+                }
+                if (scribe && pair) {
+                    rio.inv[ln_] = local ? pos : -1;
+                    rio.ids_out[ln_] = id_j;
+                    rio.w_out[ln_] = wl[ln_];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            } else {
             if (rio.r_E <= 64) {
                 constexpr int PER = 4;   // a wave's tokens four at a time, their logits requested together
                 for (int t0 = wv_; t0 < Tn; t0 += PER * NW) {
@@ -646,23 +698,31 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
             // il / wl live in the buffer that inline_route() clears first (its per-expert masks): every read above
             // must have returned before any wave starts clearing
             __syncthreads();
+            }
         } else {
             if ((int)threadIdx.x < rio.P)
                 my_e = rio.ids[(int64_t)((int)threadIdx.x / k_top) * rio.ids_stride + (int)threadIdx.x % k_top] - rio.e_first;
         }
         if (my_e >= rio.E_local) my_e = -1;
-        inline_route(rio, my_e, mt_rows, reinterpret_cast<uint32_t*>(red), rt, threadIdx.x, THREADS);
+        if (!(INLINE == 2 && rio.P == rio.r_k && rio.r_E <= 64))   // (a single token has bucketed its pairs above)
+            inline_route(rio, my_e, mt_rows, reinterpret_cast<uint32_t*>(red), rt, threadIdx.x, THREADS);
     } else {
         // The first 64 entries of the tile -> expert table are requested right away, one per lane, together with
         // the tile count, so the first weight address is one memory round trip away instead of two; later lookups
         // of those entries are lane reads.
         te_lane = ((int)(threadIdx.x & 63) < table_len) ? tile_expert[threadIdx.x & 63] : 0;
+        // likewise the first 64 tiles' first rows and the first 64 experts' list offsets (the table holds E_local + 1 of
+        // them, at least table_len): the activations of the first item are then one trip behind this one, not two
+        tm_lane = ((int)(threadIdx.x & 63) < table_len) ? tile_m0[threadIdx.x & 63] : 0;
+        of_lane = ((int)(threadIdx.x & 63) < off_len) ? offsets[threadIdx.x & 63] : 0;
     }
     M355_PRO_STAMP(0)   /* routing done (or the tile table requested) */
 #define M355_TILE_EXPERT(TT) (INLINE ? __builtin_amdgcn_readfirstlane(rt->tile_e[(TT)]) \
                                      : (((TT) < 64) ? __builtin_amdgcn_readlane(te_lane, (TT)) : tile_expert[(TT)]))
-#define M355_TILE_M0(TT) (INLINE ? __builtin_amdgcn_readfirstlane(rt->tile_m0[(TT)]) : tile_m0[(TT)])
-#define M355_OFFSET(E) (INLINE ? __builtin_amdgcn_readfirstlane(rt->off[(E)]) : offsets[(E)])
+#define M355_TILE_M0(TT) (INLINE ? __builtin_amdgcn_readfirstlane(rt->tile_m0[(TT)]) \
+                                 : (((TT) < 64) ? __builtin_amdgcn_readlane(tm_lane, (TT)) : tile_m0[(TT)]))
+#define M355_OFFSET(E) (INLINE ? __builtin_amdgcn_readfirstlane(rt->off[(E)]) \
+                               : (((E) < off_len) ? __builtin_amdgcn_readlane(of_lane, (E)) : offsets[(E)]))
 #define M355_PAIR_AT(POS) (INLINE ? rt->tok[(POS)] : sorted[(POS)])
     const int NB = K / 64, NP = R / 32;
     const int NPG = (NP + PAIRS - 1) / PAIRS;
