@@ -118,6 +118,98 @@ __global__ __launch_bounds__(DENSE_THREADS) void dense_stream_kernel(const half_
 #undef DENSE_LOAD
 }
 
+// The same product when a workgroup's share of W is at most two row tiles (N <= 32 rows per CU: every projection of a
+// gpt-oss layer): the rows are dealt out four at a time, so every CU streams the same number of bytes whatever N is (5120
+// rows are 20 per CU instead of one or two whole 16-row tiles, 2880 rows 8 or 12 instead of 16 on 180 of the CUs), and
+// ALL of a workgroup's weights are requested at once, ahead of the activations: one trip to memory per launch instead
+// of one per item.  Lanes whose row lies past the workgroup's share load nothing.  Same K-parts, same order of sums:
+// the bits of dense_stream_kernel.
+template <int STEPS, int NT, int TILES>
+__global__ __launch_bounds__(DENSE_THREADS) void dense_rows_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
+                                                                   const half_t* __restrict__ bias,
+                                                                   const half_t* __restrict__ resid, int T, int N, int K,
+                                                                   half_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float red[TILES][DENSE_KPARTS][NT][64][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int NB = K / 64, units = N / 4;
+    const int r0 = 4 * (int)((int64_t)blockIdx.x * units / gridDim.x), r1 = 4 * (int)((int64_t)(blockIdx.x + 1) * units / gridDim.x);
+    if (r0 >= r1) return;
+    const int b0 = q * NB / DENSE_KPARTS, b1 = (q + 1) * NB / DENSE_KPARTS;   // this wave's blocks
+
+    // A fragments of both tiles: row r0 + 16 tile + (lane & 15), columns 64 * block + 16 * g (+ 8)
+    u32x4_t A[TILES][STEPS][2];
+#pragma unroll
+    for (int tile = 0; tile < TILES; tile++) {
+        const int row = r0 + 16 * tile + n;
+        const unsigned char* rp = reinterpret_cast<const unsigned char*>(w) + (size_t)min(row, r1 - 1) * K * 2 + 32 * g;
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+            A[tile][s][0] = z;
+            A[tile][s][1] = z;
+            if (row < r1) {
+                const u32x4_t* src = reinterpret_cast<const u32x4_t*>(rp + (size_t)min(b0 + s, NB - 1) * 128);
+                A[tile][s][0] = __builtin_nontemporal_load(src);
+                A[tile][s][1] = __builtin_nontemporal_load(src + 1);
+            }
+        }
+    }
+    // B fragments: token (16 * tile + n, clamped), the same columns; zero where the slot is outside this wave's part
+    half8_t xb[NT][STEPS][2];
+#pragma unroll
+    for (int tt = 0; tt < NT; tt++) {
+        const int tok = min(16 * tt + n, T - 1);
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            const half8_t* src = reinterpret_cast<const half8_t*>(x + (int64_t)tok * K + min(b0 + s, NB - 1) * 64 + 16 * g);
+            const bool live = b0 + s < b1;
+            const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+            xb[tt][s][0] = live ? src[0] : z;
+            xb[tt][s][1] = live ? src[1] : z;
+        }
+    }
+#pragma unroll
+    for (int tile = 0; tile < TILES; tile++) {
+        if (r0 + 16 * tile >= r1) break;
+        float4_t acc[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; tt++) acc[tt] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            const half8_t a0 = __builtin_bit_cast(half8_t, A[tile][s][0]), a1 = __builtin_bit_cast(half8_t, A[tile][s][1]);
+#pragma unroll
+            for (int tt = 0; tt < NT; tt++) {
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, xb[tt][s][0], acc[tt], 0, 0, 0);
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, xb[tt][s][1], acc[tt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < NT; tt++) *reinterpret_cast<float4_t*>(red[tile][q][tt][lane]) = acc[tt];
+    }
+    dense_barrier();
+    // wave `tile` finishes tile `tile`: the K-parts summed in part order, then bias, rounding, residual
+    if (q < TILES && r0 + 16 * q < r1) {
+#pragma unroll
+        for (int tt = 0; tt < NT; tt++) {
+            float4_t acc = *reinterpret_cast<const float4_t*>(red[q][0][tt][lane]);
+#pragma unroll
+            for (int qq = 1; qq < DENSE_KPARTS; qq++) acc += *reinterpret_cast<const float4_t*>(red[q][qq][tt][lane]);
+            const int tok = 16 * tt + n;
+            const int col = r0 + 16 * q + 4 * g;   // accumulator rows 4g..4g+3 of the tile = output columns
+            if (tok < T && col < r1) {
+                half4_t o;
+                const half4_t bv = bias ? *reinterpret_cast<const half4_t*>(bias + col) : half4_t{0, 0, 0, 0};
+#pragma unroll
+                for (int r = 0; r < 4; r++) o[r] = (half_t)(acc[r] + (float)bv[r]);
+                if (resid) o = o + *reinterpret_cast<const half4_t*>(resid + (int64_t)tok * N + col);
+                *reinterpret_cast<half4_t*>(out + (int64_t)tok * N + col) = o;
+            }
+        }
+    }
+}
+
 // A handful of tokens (T <= 4: single-sequence decode).  The 16-row tiles of the kernel above are too coarse a unit
 // there: 5120 rows are 320 tiles for 256 CUs, two rounds for 1.25 rounds of work, and a CU cannot stream faster than its
 // own share of the HBM bandwidth.  Here the unit is half a row of W: a workgroup owns a contiguous run of rows (N / grid,
@@ -383,6 +475,20 @@ static int launch_dense(const half_t* x, const half_t* w, const half_t* bias, co
     return 0;
 }
 
+template <int STEPS, int NT>
+static int launch_dense_rows(const half_t* x, const half_t* w, const half_t* bias, const half_t* resid, int T, int N, int K,
+                             half_t* out, int cus, hipStream_t st) {
+    const int units = N / 4;
+    const int grid = units < cus ? units : cus;
+    const int max_rows = 4 * ((units + grid - 1) / grid);
+    if (max_rows <= 16)
+        dense_rows_kernel<STEPS, NT, 1><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, resid, T, N, K, out);
+    else
+        dense_rows_kernel<STEPS, NT, 2><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, resid, T, N, K, out);
+    M355_LAUNCH_CHECK("dense_rows_kernel");
+    return 0;
+}
+
 // many tokens: the tiled kernel of dense_tile.hip
 int launch_dense_tile(const half_t* x, const half_t* w, const half_t* bias, const half_t* resid, int T, int N, int K,
                       half_t* out, int cus, hipStream_t st);
@@ -419,6 +525,13 @@ extern "C" int m355_linear_f16(const void* x_f16, int T, const void* w_f16, cons
         }
     }
     const bool small_k = K <= 64 * DENSE_KPARTS * 6;
+#ifndef M355_EXP_NO_DENSE_ROWS
+    // at most 32 rows of W per CU: every CU takes the same share of the rows and requests all of it at once
+    if (T <= 32 && N <= 32 * cus && (small_k || N <= 16 * cus || T <= 16)) {
+        if (T <= 16) return small_k ? launch_dense_rows<6, 1>(x, w, b, r, T, N, K, out, cus, st) : launch_dense_rows<8, 1>(x, w, b, r, T, N, K, out, cus, st);
+        return small_k ? launch_dense_rows<6, 2>(x, w, b, r, T, N, K, out, cus, st) : launch_dense_rows<8, 2>(x, w, b, r, T, N, K, out, cus, st);
+    }
+#endif
     // 32 tokens per pass; more tokens re-stream W once per pass (decode batches above 32 are the exception here)
     for (int t0 = 0; t0 < T; t0 += 32) {
         const int tn = T - t0 < 32 ? T - t0 : 32;

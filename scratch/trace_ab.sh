@@ -10,7 +10,7 @@ for v in "$@"; do
   python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-for r in rows[:8]:
+for r in rows[:int(__import__("os").environ.get("TRACE_ROWS", "8"))]:
     print('%-90s n=%6s avg %8.2f us  min %8.2f  max %8.2f' % (r['Name'][:90], r['Calls'], float(r['AverageNs'])/1e3, float(r['MinNs'])/1e3, float(r['MaxNs'])/1e3))
 PY
 done
