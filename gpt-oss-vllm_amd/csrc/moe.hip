@@ -1200,7 +1200,7 @@ int moe_device_init(int dev) {
 }
 
 #ifndef M355_FOLD_MAX_PAIRS
-#define M355_FOLD_MAX_PAIRS 32
+#define M355_FOLD_MAX_PAIRS 12
 #endif
 constexpr int FOLD_COMBINE_MAX_PAIRS = M355_FOLD_MAX_PAIRS;   // (token, k) pairs up to which the down launch also combines
 
@@ -1446,8 +1446,10 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
     }
     // The combine step rides in the down launch when both GEMM stages run here as streaming-kernel launches (gate_up clears
     // the counters the down launch counts on) and the batch is small: the y values then travel through memory as
-    // device-scope 2-byte stores, which costs more than the saved launch from a few dozen (token, k) pairs on (measured:
-    // 2.7 us per layer gained at 4 pairs, 6 us lost at 128).  M355_FLAG_FOLD_COMBINE folds at any size.
+    // device-scope 4-byte stores that every wave waits out, and the workgroups that finish a column group last make an
+    // acquire and one more trip to memory, which costs more than the saved launch from 16 (token, k) pairs on (measured:
+    // 1 us per layer gained at 4 pairs, 0.25 at 12; 0.7 lost at 16, 1.7 at 32, 6 at 128).  M355_FLAG_FOLD_COMBINE folds
+    // at any size.
     const bool fold_combine = !tiled && (P <= FOLD_COMBINE_MAX_PAIRS || (flags & M355_FLAG_FOLD_COMBINE)) && H / 64 <= MOE_KPARTS * MOE_CHUNK && FF / 64 <= MOE_KPARTS * MOE_CHUNK && H / 32 <= SYNC_PG_COUNTERS &&
                               !(flags & (M355_FLAG_SKIP_GATE_UP | M355_FLAG_SKIP_DOWN | M355_FLAG_SKIP_COMBINE | M355_FLAG_SEPARATE_COMBINE));
     const CombineIO cio_gu = {nullptr, nullptr, nullptr, 0, 0, 0, fold_combine ? ws.pg_done : nullptr};

@@ -52,7 +52,7 @@ typedef void* m355_stream_t; /* a hipStream_t (NULL = the default stream) */
    makes the choice. */
 #define M355_FLAG_STREAM_WIDE 0x4000
 /* The combine step (out[t] = sum over k of w * y) rides in the down stage's launch when the streaming kernel runs both
-   stages on a small batch (up to 32 (token, k) pairs); SEPARATE_COMBINE makes it its own launch there too, as it is for
+   stages on a small batch (up to 12 (token, k) pairs); SEPARATE_COMBINE makes it its own launch there too, as it is for
    larger batches and after the tile kernel; FOLD_COMBINE folds it at any batch size the streaming kernel takes.  Same
    bits every way. */
 #define M355_FLAG_SEPARATE_COMBINE 0x8000

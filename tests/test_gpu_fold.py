@@ -62,7 +62,7 @@ def test_folded_combine_on_an_expert_shard(ref, m355, cuda):
 
 def test_folded_combine_under_load(ref, m355, cuda):
     """The hand-off of y between workgroups inside the down launch, where an idle chip would hide a missing wait: the
-    default (folded) form for decode batches of 1, 4 and 8 against the separate combine launch, bit for bit, 240 calls
+    folded form (the default up to 3 tokens at top-4, forced here) for decode batches of 1, 4 and 8 against the separate combine launch, bit for bit, 240 calls
     back to back on one workspace, while a second stream keeps the chip busy with streaming kernels of uneven sizes (some
     fill every CU, some only a part).  Consecutive calls carry different inputs, so a y row left over from the call
     before would belong to another token; every word of every output is compared."""
@@ -96,7 +96,7 @@ def test_folded_combine_under_load(ref, m355, cuda):
         xd, idd, wd, _ = cases[(i * 7) % len(cases)]      # 7 is coprime to 18: sizes and inputs change from call to call
         outs[i] = torch.full_like(cases[(i * 7) % len(cases)][3], float("nan"))
         m355.moe_nf4_forward(xd, idd, wd, *tl, E_local=E, e_first=0, H=H, FF=FF, workspace=ws, out=outs[i],
-                             flags=m355.FLAG_FP16_COMBINE)
+                             flags=m355.FLAG_FP16_COMBINE | m355.FLAG_FOLD_COMBINE)
     torch.cuda.synchronize()
     bad = [i for i in range(CALLS) if not torch.equal(outs[i].view(torch.int16), cases[(i * 7) % len(cases)][3].view(torch.int16))]
     assert not bad, f"{len(bad)} of {CALLS} folded calls differ from the separate combine, first at call {bad[0]}"
