@@ -422,6 +422,141 @@ __global__ __launch_bounds__(DENSE_THREADS) void qkv_rope_gemv_kernel(const half
     }
 }
 
+// The q/k/v projection of 5 to 32 tokens with rotary embedding and cache write in the projection's launch: the kernel
+// above with the rows of a tile taken as 8 pairs (d, d + D/2) of a head -- tile rows 0..7 the first halves, 8..15 their
+// partners -- so the lane that finishes rows 4g..4g+3 of a tile (g < 2) finds the partners' sums under lane + 32 of the
+// same reduction buffers.  The pairs are dealt out four at a time (a lane's four consecutive d share one 8-byte store);
+// a workgroup takes at most 16 pairs = two tiles.  Same K-parts, same order of sums, same roundings: the bits of
+// m355_linear_f16 followed by m355_rope_kv_write.
+template <int STEPS, int NT>
+__global__ __launch_bounds__(DENSE_THREADS) void qkv_rope_rows_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
+                                                                      const half_t* __restrict__ bias, int T, int N, int K,
+                                                                      RopeKvArgs ra) {
+    constexpr int TILES = 2;
+    __shared__ __attribute__((aligned(16))) float red[TILES][DENSE_KPARTS][NT][64][4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const int NB = K / 64, half_d = ra.D / 2, units = N / 8;   // a unit = 4 pairs
+    const int p0 = 4 * (int)((int64_t)blockIdx.x * units / gridDim.x), p1 = 4 * (int)((int64_t)(blockIdx.x + 1) * units / gridDim.x);
+    if (p0 >= p1) return;
+    const int b0 = q * NB / DENSE_KPARTS, b1 = (q + 1) * NB / DENSE_KPARTS;
+    // row of W behind tile row n of tile `tile`: pair p0 + 8 tile + (n & 7), its first (n < 8) or second half
+    auto pair_row = [&](int p, int second) {
+        const int head = p / half_d, d = p - head * half_d;
+        return head * ra.D + d + second * half_d;
+    };
+    u32x4_t A[TILES][STEPS][2];
+#pragma unroll
+    for (int tile = 0; tile < TILES; tile++) {
+        const int p = p0 + 8 * tile + (n & 7);
+        const unsigned char* rp = reinterpret_cast<const unsigned char*>(w) + (size_t)pair_row(min(p, p1 - 1), n >> 3) * K * 2 + 32 * g;
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+            A[tile][s][0] = z;
+            A[tile][s][1] = z;
+            if (p < p1) {
+                const u32x4_t* src = reinterpret_cast<const u32x4_t*>(rp + (size_t)min(b0 + s, NB - 1) * 128);
+                A[tile][s][0] = __builtin_nontemporal_load(src);
+                A[tile][s][1] = __builtin_nontemporal_load(src + 1);
+            }
+        }
+    }
+    half8_t xb[NT][STEPS][2];
+#pragma unroll
+    for (int tt = 0; tt < NT; tt++) {
+        const int tok = min(16 * tt + n, T - 1);
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            const half8_t* src = reinterpret_cast<const half8_t*>(x + (int64_t)tok * K + min(b0 + s, NB - 1) * 64 + 16 * g);
+            const bool live = b0 + s < b1;
+            const half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+            xb[tt][s][0] = live ? src[0] : z;
+            xb[tt][s][1] = live ? src[1] : z;
+        }
+    }
+#pragma unroll
+    for (int tile = 0; tile < TILES; tile++) {
+        if (p0 + 8 * tile >= p1) break;
+        float4_t acc[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; tt++) acc[tt] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            const half8_t a0 = __builtin_bit_cast(half8_t, A[tile][s][0]), a1 = __builtin_bit_cast(half8_t, A[tile][s][1]);
+#pragma unroll
+            for (int tt = 0; tt < NT; tt++) {
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, xb[tt][s][0], acc[tt], 0, 0, 0);
+                acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, xb[tt][s][1], acc[tt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < NT; tt++) *reinterpret_cast<float4_t*>(red[tile][q][tt][lane]) = acc[tt];
+    }
+    dense_barrier();
+    // wave (tile, tt) = (q & 1, q >> 1) finishes: lanes g < 2 hold pairs 4g .. 4g + 3 of the tile, first halves under
+    // their own lane, partners under lane + 32
+    const int tile = q & 1, tt = q >> 1;
+    if (tt < NT && g < 2 && p0 + 8 * tile + 4 * g < p1) {
+        float4_t fa = *reinterpret_cast<const float4_t*>(red[tile][0][tt][lane]);
+        float4_t fb = *reinterpret_cast<const float4_t*>(red[tile][0][tt][lane + 32]);
+#pragma unroll
+        for (int qq = 1; qq < DENSE_KPARTS; qq++) {
+            fa += *reinterpret_cast<const float4_t*>(red[tile][qq][tt][lane]);
+            fb += *reinterpret_cast<const float4_t*>(red[tile][qq][tt][lane + 32]);
+        }
+        const int tok = 16 * tt + n;
+        if (tok < T) {
+            const int p = p0 + 8 * tile + 4 * g;                 // first of the lane's four pairs (one head: half_d % 4 == 0)
+            const int ra_row = pair_row(p, 0), rb_row = ra_row + half_d;
+            const int head = ra_row / ra.D, d = ra_row - head * ra.D;
+            half4_t va, vb;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                va[r] = (half_t)(fa[r] + (bias ? (float)bias[ra_row + r] : 0.f));
+                vb[r] = (half_t)(fb[r] + (bias ? (float)bias[rb_row + r] : 0.f));
+            }
+            const int64_t slot = ra.slots[tok];
+            const int64_t cache_row = slot >= 0 ? ((slot / ra.block_size) * ra.block_size + slot % ra.block_size) * (int64_t)ra.Hkv * ra.D : -1;
+            half_t* dst = nullptr;
+            if (head < ra.Hq + ra.Hkv) {
+                const int pos = min(max(ra.positions[tok], 0), ra.max_pos - 1);
+                const half4_t cs = *reinterpret_cast<const half4_t*>(ra.cos_t + (int64_t)pos * half_d + d);
+                const half4_t sn = *reinterpret_cast<const half4_t*>(ra.sin_t + (int64_t)pos * half_d + d);
+                half4_t o1, o2;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    half_t u1, u2;
+                    rope_rotate(va[r], vb[r], cs[r], sn[r], u1, u2);
+                    o1[r] = u1;
+                    o2[r] = u2;
+                }
+                va = o1;
+                vb = o2;
+                if (head < ra.Hq) dst = ra.q_out + ((int64_t)tok * ra.Hq + head) * ra.D;
+                else if (cache_row >= 0) dst = ra.kcache + cache_row + (head - ra.Hq) * ra.D;
+            } else if (cache_row >= 0) {
+                dst = ra.vcache + cache_row + (head - ra.Hq - ra.Hkv) * ra.D;
+            }
+            if (dst) {
+                *reinterpret_cast<half4_t*>(dst + d) = va;
+                *reinterpret_cast<half4_t*>(dst + d + half_d) = vb;
+            }
+        }
+    }
+}
+
+template <int STEPS, int NT>
+static int launch_qkv_rope_rows(const half_t* x, const half_t* w, const half_t* bias, int T, int N, int K, const RopeKvArgs& ra,
+                                int cus, hipStream_t st) {
+    const int units = N / 8;
+    const int grid = units < cus ? units : cus;
+    qkv_rope_rows_kernel<STEPS, NT><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, T, N, K, ra);
+    M355_LAUNCH_CHECK("qkv_rope_rows_kernel");
+    return 0;
+}
+
 template <int TN, int NORM>
 static int launch_qkv_rope(const half_t* x, const half_t* w, const half_t* bias, int N, int K, const RopeKvArgs& ra,
                            const NormArgs& na, int cus, hipStream_t st) {
@@ -571,8 +706,27 @@ extern "C" int m355_qkv_rope_kv_write(const void* x_f16, int T, const void* wqkv
         hipStream_t st = (hipStream_t)stream;
         return launch_qkv_rope_t<0>(T, x, w, b, N, K, ra, NormArgs{}, cus, st);
     }
+    // up to 32 tokens, at most 16 (d, d + D/2) pairs of W per CU: still one launch
+    {
+        int dev = 0, cus = 0;
+        if (int rc = hip_status(hipGetDevice(&dev), "hipGetDevice")) return rc;
+        if (int rc = hip_status(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute")) return rc;
+        if (cus <= 0) cus = 256;
+        const int units = N / 8, grid = units < cus ? units : cus;
+        const bool small_k = K <= 64 * DENSE_KPARTS * 6;
+        if (T <= 32 && (D % 8) == 0 && K <= 64 * DENSE_KPARTS * 8 && (units + grid - 1) / grid <= 4 && (small_k || T <= 16) &&
+            aligned(x_f16, 16) && aligned(wqkv_f16, 16) && (!bqkv_f16 || aligned(bqkv_f16, 2)) && aligned(cos_f16, 8) &&
+            aligned(sin_f16, 8) && aligned(q_out_f16, 8) && aligned(kcache_f16, 8) && aligned(vcache_f16, 8)) {
+            const RopeKvArgs ra = {(const half_t*)cos_f16, (const half_t*)sin_f16, positions, slots, Hq, Hkv, D, block_size, max_pos,
+                                   (half_t*)q_out_f16, (half_t*)kcache_f16, (half_t*)vcache_f16};
+            const half_t *x = (const half_t*)x_f16, *w = (const half_t*)wqkv_f16, *b = (const half_t*)bqkv_f16;
+            hipStream_t st = (hipStream_t)stream;
+            if (T <= 16) return small_k ? launch_qkv_rope_rows<6, 1>(x, w, b, T, N, K, ra, cus, st) : launch_qkv_rope_rows<8, 1>(x, w, b, T, N, K, ra, cus, st);
+            return launch_qkv_rope_rows<6, 2>(x, w, b, T, N, K, ra, cus, st);
+        }
+    }
     // more tokens: the two launches, through the caller's qkv buffer
-    if (!qkv_scratch_f16) return fail(-1, "m355_qkv_rope_kv_write: more than %d tokens need the qkv scratch buffer", GEMV_MAX_T);
+    if (!qkv_scratch_f16) return fail(-1, "m355_qkv_rope_kv_write: this many tokens (or this shape) need the qkv scratch buffer");
     if (int rc = m355_linear_f16(x_f16, T, wqkv_f16, bqkv_f16, N, K, nullptr, qkv_scratch_f16, stream)) return rc;
     return m355_rope_kv_write(qkv_scratch_f16, cos_f16, sin_f16, positions, slots, T, Hq, Hkv, D, block_size, max_pos, q_out_f16,
                               kcache_f16, vcache_f16, stream);

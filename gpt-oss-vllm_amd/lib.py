@@ -646,7 +646,7 @@ def rope_kv_write(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, posit
 def qkv_rope_kv_write(x: torch.Tensor, wqkv: torch.Tensor, bqkv: Optional[torch.Tensor], cos: torch.Tensor, sin: torch.Tensor,
                       positions: torch.Tensor, slots: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, *, Hq: int,
                       Hkv: int, D: int, q_out: Optional[torch.Tensor] = None, qkv_scratch: Optional[torch.Tensor] = None):
-    """The q/k/v projection of x [T][K] followed by rope_kv_write on its result, in one call (one launch up to 4 tokens;
+    """The q/k/v projection of x [T][K] followed by rope_kv_write on its result, in one call (one launch up to 32 tokens;
     beyond, the two launches through qkv_scratch [T][(Hq + 2 Hkv) D], allocated here when missing).  The bits of
     linear_f16 then rope_kv_write.  m355_qkv_rope_kv_write."""
     T, K = x.shape

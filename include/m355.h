@@ -331,9 +331,10 @@ M355_API int m355_rope_kv_write(const void* qkv_f16, const void* cos_f16, const 
 /*
  * m355_qkv_rope_kv_write: the q/k/v projection (m355_linear_f16 with wqkv [(Hq + 2*Hkv)*D][K], bias bqkv or NULL) and
  *   m355_rope_kv_write on its result in one call: GptOssAttention.forward up to the attention itself
- *   (modeling_gpt_oss.py:262-273 with _apply_rotary_emb, :295-320 for the cache update).  Up to 4 tokens it is one launch
- *   (the projection's kernel rotates and stores the pairs it has just summed; qkv_scratch may be NULL); beyond, the two
- *   launches through qkv_scratch [T][(Hq + 2*Hkv)*D].  The same bits either way.
+ *   (modeling_gpt_oss.py:262-273 with _apply_rotary_emb, :295-320 for the cache update).  Up to 32 tokens it is one launch
+ *   (the projection's kernel rotates and stores the pairs it has just summed: a dot-product form up to 4 tokens, a
+ *   matrix-core form beyond, for shapes with at most 16 (d, d + D/2) pairs of rows per CU; qkv_scratch may be NULL
+ *   there); otherwise the two launches through qkv_scratch [T][(Hq + 2*Hkv)*D].  The same bits either way.
  */
 M355_API int m355_qkv_rope_kv_write(const void* x_f16, int T, const void* wqkv_f16, const void* bqkv_f16, int K,
                                     const void* cos_f16, const void* sin_f16, const int32_t* positions, const int64_t* slots,

@@ -145,9 +145,14 @@ def test_gpu_linear_f16(T, N, K, bias, resid):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("T,Hq,Hkv,D,K,bias", [(1, 64, 8, 64, 2880, True), (4, 64, 8, 64, 2880, True), (3, 4, 2, 32, 192, False),
-                                               (2, 6, 3, 16, 4096, True), (7, 8, 4, 64, 256, True)])
+                                               (2, 6, 3, 16, 4096, True), (7, 8, 4, 64, 256, True),
+                                               # 5 to 32 tokens: the MFMA form with the rotation in its epilogue
+                                               (32, 64, 8, 64, 2880, True), (17, 64, 8, 64, 2880, False), (5, 64, 8, 64, 2880, True),
+                                               (16, 4, 2, 32, 4096, True), (9, 3, 1, 16, 320, False), (32, 8, 8, 64, 3072, True),
+                                               # beyond: the two launches
+                                               (33, 8, 2, 64, 256, True), (20, 4, 2, 32, 4096, False)])
 def test_gpu_qkv_rope_kv_write_equals_the_two_launches(T, Hq, Hkv, D, K, bias):
-    """m355_qkv_rope_kv_write (one launch up to 4 tokens) against m355_linear_f16 followed by m355_rope_kv_write: q, and
+    """m355_qkv_rope_kv_write (one launch up to 32 tokens) against m355_linear_f16 followed by m355_rope_kv_write: q, and
     every word of both caches (a token with a negative slot writes nothing), bit for bit."""
     from gpt_oss_vllm_amd import lib
     cuda = torch.device("cuda:0")
