@@ -155,7 +155,7 @@ class DecodeStep:
             add(False, lambda lay=lay: lib.paged_attn_decode(lay["q"], lay["kc"], lay["vc"], self.block_tables, self.ctx_lens,
                                                              max_ctx=self.ctx, scale=D ** -0.5, out=lay["attn_out"]))
             if ep.world == 1 and not ep.force_exchange:
-                # router and experts in one library call (up to 8 tokens gate_up computes the router itself)
+                # router and experts in one library call (up to 24 tokens: logits launch + top-k inside gate_up)
                 add(False, lambda lay=lay, ep=ep: lib.moe_nf4_forward_routed(
                     lay["x"], lay["wr"], None, TOPK, *ep.weights, E_local=ep.epr, e_first=0, H=H, FF=FF, ids=lay["ids"],
                     w=lay["w"], workspace=ep.workspace, out=lay["out"], flags=ep.flags))
