@@ -120,6 +120,109 @@ __global__ __launch_bounds__(ROUTE_THREADS) void moe_route_kernel(const int32_t*
     }
 }
 
+// The same for a prompt's tens of thousands of pairs, over ROUTE_WGS workgroups in two launches: every workgroup counts
+// its contiguous share of the pairs per expert (moe_route_count_kernel: one row of `hist` each); then every workgroup
+// reads all rows, from which the list offsets (column sums, scanned) and its own first position in every expert's list
+// (the rows above its own) follow, and places its pairs (moe_route_place_kernel; workgroup 0 also writes the tables).
+// As in the single-workgroup kernel, the order of an expert's pairs within its list is whatever the atomics give: no
+// result depends on it.
+constexpr int ROUTE_WGS = 32;
+constexpr int ROUTE_PARALLEL_MIN_PAIRS = 4096;
+
+__global__ __launch_bounds__(ROUTE_THREADS) void moe_route_count_kernel(const int32_t* __restrict__ ids, int ids_stride, int k_top,
+                                                                        int P, int E_local, int e_first,
+                                                                        int32_t* __restrict__ hist) {
+    __shared__ int cnt[ROUTE_MAX_E];
+    const int tid = threadIdx.x;
+    const int chunk = (P + ROUTE_WGS - 1) / ROUTE_WGS;
+    const int pa = blockIdx.x * chunk, pb = min(pa + chunk, P);
+    for (int e = tid; e < E_local; e += ROUTE_THREADS) cnt[e] = 0;
+    __syncthreads();
+    for (int p = pa + tid; p < pb; p += ROUTE_THREADS) {
+        const int e = ids[(int64_t)(p / k_top) * ids_stride + p % k_top] - e_first;
+        if (e >= 0 && e < E_local) atomicAdd(&cnt[e], 1);
+    }
+    __syncthreads();
+    for (int e = tid; e < E_local; e += ROUTE_THREADS) hist[blockIdx.x * E_local + e] = cnt[e];
+}
+
+__global__ __launch_bounds__(ROUTE_THREADS) void moe_route_place_kernel(const int32_t* __restrict__ ids, int ids_stride, int k_top,
+                                                                        int P, int E_local, int e_first,
+                                                                        const int32_t* __restrict__ hist,
+                                                                        int32_t* __restrict__ n_active,
+                                                                        int32_t* __restrict__ offsets,
+                                                                        int32_t* __restrict__ active,
+                                                                        int32_t* __restrict__ sorted,
+                                                                        int32_t* __restrict__ inv, int mt_rows,
+                                                                        int32_t* __restrict__ n_tiles,
+                                                                        int32_t* __restrict__ tile_expert,
+                                                                        int32_t* __restrict__ tile_m0) {
+    __shared__ int cnt[ROUTE_MAX_E];    // pairs of the expert over all workgroups
+    __shared__ int cur[ROUTE_MAX_E];    // first the pairs of the expert in the workgroups above this one, then the running position
+    const int tid = threadIdx.x;
+    const bool scribe = blockIdx.x == 0;
+    for (int e = tid; e < E_local; e += ROUTE_THREADS) {
+        int tot = 0, above = 0;
+#pragma unroll 8
+        for (int g = 0; g < ROUTE_WGS; g++) {
+            const int c = hist[g * E_local + e];
+            tot += c;
+            above += g < (int)blockIdx.x ? c : 0;
+        }
+        cnt[e] = tot;
+        cur[e] = above;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        // wave 0: lane l owns experts [l*C, (l+1)*C); exclusive wave scans give where its lists start
+        const int C = (E_local + 63) / 64;
+        const int ea = min(tid * C, E_local), eb = min(ea + C, E_local);
+        int s_cnt = 0, s_act = 0, s_tiles = 0;
+        for (int e = ea; e < eb; e++) {
+            s_cnt += cnt[e];
+            s_act += cnt[e] > 0;
+            s_tiles += (cnt[e] + mt_rows - 1) / mt_rows;
+        }
+        int run = s_cnt, na = s_act, nt = s_tiles;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int a1 = __shfl_up(run, o, 64), a2 = __shfl_up(na, o, 64), a3 = __shfl_up(nt, o, 64);
+            if (tid >= o) { run += a1; na += a2; nt += a3; }
+        }
+        if (tid == 63 && scribe) {
+            offsets[E_local] = run;
+            *n_active = na;
+            *n_tiles = nt;
+        }
+        run -= s_cnt; na -= s_act; nt -= s_tiles;   // exclusive
+        for (int e = ea; e < eb; e++) {
+            cur[e] += run;
+            if (scribe) {
+                offsets[e] = run;
+                if (cnt[e] > 0) active[na] = e;
+                for (int m0 = 0; m0 < cnt[e]; m0 += mt_rows) {
+                    tile_expert[nt] = e;
+                    tile_m0[nt++] = m0;
+                }
+            }
+            na += cnt[e] > 0;
+            run += cnt[e];
+        }
+    }
+    __syncthreads();
+    const int chunk = (P + ROUTE_WGS - 1) / ROUTE_WGS;
+    const int pa = blockIdx.x * chunk, pb = min(pa + chunk, P);
+    for (int p = pa + tid; p < pb; p += ROUTE_THREADS) {
+        const int e = ids[(int64_t)(p / k_top) * ids_stride + p % k_top] - e_first;
+        int pos = -1;
+        if (e >= 0 && e < E_local) {
+            pos = atomicAdd(&cur[e], 1);
+            sorted[pos] = p;
+        }
+        inv[p] = pos;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fused dequant GEMM
 // ------------------------------------------------------------------------------------------------
@@ -1428,10 +1531,22 @@ static int moe_forward_impl(const void* x_f16, int T, const int32_t* ids, const 
     const RouteIO rio = {ids, rows.ids_stride, P, E_local, e_first, ws.n_active, ws.offsets, ws.active, ws.sorted, ws.inv, ws.n_tiles, ws.tile_expert, ws.tile_m0,
                          router.logits ? (const half_t*)router.logits : ws.y, router.E_global, k, const_cast<int32_t*>(ids), const_cast<float*>(w)};
     if (!(flags & M355_FLAG_SKIP_ROUTE) && !inline_route) {
-        moe_route_kernel<<<dim3(1), dim3(ROUTE_THREADS), 0, st>>>(ids, rows.ids_stride, k, P, E_local, e_first, ws.n_active, ws.offsets,
-                                                                  ws.active, ws.sorted, ws.inv, mt_rows, ws.n_tiles,
-                                                                  ws.tile_expert, ws.tile_m0);
-        M355_LAUNCH_CHECK("moe_route_kernel");
+        // (the per-workgroup counts of the parallel form lie in the h rows, which nothing touches before the gate_up stage)
+        if (P >= ROUTE_PARALLEL_MIN_PAIRS && (size_t)ROUTE_WGS * E_local * 4 <= (size_t)2 * P * FF && !(flags & M355_FLAG_SKIP_GATE_UP)) {
+            int32_t* hist = reinterpret_cast<int32_t*>(ws.h);
+            moe_route_count_kernel<<<dim3(ROUTE_WGS), dim3(ROUTE_THREADS), 0, st>>>(ids, rows.ids_stride, k, P, E_local, e_first, hist);
+            M355_LAUNCH_CHECK("moe_route_count_kernel");
+            moe_route_place_kernel<<<dim3(ROUTE_WGS), dim3(ROUTE_THREADS), 0, st>>>(ids, rows.ids_stride, k, P, E_local, e_first, hist,
+                                                                                  ws.n_active, ws.offsets, ws.active, ws.sorted,
+                                                                                  ws.inv, mt_rows, ws.n_tiles, ws.tile_expert,
+                                                                                  ws.tile_m0);
+            M355_LAUNCH_CHECK("moe_route_place_kernel");
+        } else {
+            moe_route_kernel<<<dim3(1), dim3(ROUTE_THREADS), 0, st>>>(ids, rows.ids_stride, k, P, E_local, e_first, ws.n_active, ws.offsets,
+                                                                      ws.active, ws.sorted, ws.inv, mt_rows, ws.n_tiles,
+                                                                      ws.tile_expert, ws.tile_m0);
+            M355_LAUNCH_CHECK("moe_route_kernel");
+        }
     }
     if (tiled) {
         if (int rc = tile_gemm_device_setup_once(dev)) return rc;
