@@ -616,10 +616,13 @@ static int launch_dense_rows(const half_t* x, const half_t* w, const half_t* bia
     const int units = N / 4;
     const int grid = units < cus ? units : cus;
     const int max_rows = 4 * ((units + grid - 1) / grid);
-    if (max_rows <= 16)
+    if (max_rows <= 16) {
         dense_rows_kernel<STEPS, NT, 1><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, resid, T, N, K, out);
-    else
+    } else if constexpr (STEPS == 8 && NT == 2) {
+        return fail(-2, "m355_linear_f16: two row tiles of K > 3072 for more than 16 tokens do not fit the registers");   // (the caller does not send this shape here)
+    } else {
         dense_rows_kernel<STEPS, NT, 2><<<dim3(grid), dim3(DENSE_THREADS), 0, st>>>(x, w, bias, resid, T, N, K, out);
+    }
     M355_LAUNCH_CHECK("dense_rows_kernel");
     return 0;
 }

@@ -620,6 +620,36 @@ def test_router_and_experts_in_one_call(T, E, k, bias, H, FF, ref, m355, cuda):
         assert torch.equal(ids_sh, ids0) and torch.equal(o_sh, want_sh)
 
 
+def test_timed_launch_reports_the_kernels_own_duration(ref, m355, cuda):
+    """m355_time_next_launch / m355_timed_launch_us: the next streaming-kernel launch carries its own start / stop events;
+    the duration is positive, below what an event pair around the call measures, and asking without a launch is an error."""
+    T, E, k, H, FF = 4, 8, 2, 256, 192
+    layer = ref.synth_layer(4242, E, H, FF)
+    tl = tiled_layer(m355, layer, E, H, FF, cuda)
+    x = _to_dev(ref.normal_f16(4243, (T, H)), cuda)
+    lg = ref.normal_f16(4244, (T, E), 1.5)
+    ids, w, _ = ref.router_topk(lg, np.eye(E, dtype=np.float16), None, k)
+    idd, wd = _to_dev(ids, cuda), _to_dev(w, cuda)
+    ws = torch.empty(max(256, m355.moe_workspace_bytes(T, k, H, FF, E)), dtype=torch.uint8, device=cuda)
+    only_gate_up = m355.FLAG_FP16_COMBINE | m355.FLAG_SKIP_DOWN | m355.FLAG_SKIP_COMBINE
+    m355.moe_nf4_forward(x, idd, wd, *tl, E_local=E, e_first=0, H=H, FF=FF, workspace=ws, flags=only_gate_up)
+    torch.cuda.synchronize()
+    m355.time_next_launch()
+    with pytest.raises(m355.Mi355LibraryError):
+        m355.timed_launch_us()                      # armed, but nothing launched yet
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    m355.moe_nf4_forward(x, idd, wd, *tl, E_local=E, e_first=0, H=H, FF=FF, workspace=ws, flags=only_gate_up)
+    b.record()
+    own = m355.timed_launch_us()
+    b.synchronize()
+    assert 0.5 < own < a.elapsed_time(b) * 1e3 + 1.0
+    # not armed any more: the next call launches as usual and the figure stays that of the timed launch
+    m355.moe_nf4_forward(x, idd, wd, *tl, E_local=E, e_first=0, H=H, FF=FF, workspace=ws, flags=only_gate_up)
+    torch.cuda.synchronize()
+    assert m355.timed_launch_us() == own
+
+
 @pytest.mark.parametrize("T,E,k,H,FF", [(1, 32, 4, 2880, 2880), (5, 32, 4, 256, 192), (24, 32, 4, 256, 192), (25, 32, 4, 256, 192),
                                         (7, 128, 4, 256, 192), (40, 8, 2, 256, 192), (3, 300, 6, 256, 192), (300, 32, 4, 256, 192)])
 def test_logits_and_experts_in_one_call(T, E, k, H, FF, ref, m355, cuda):
