@@ -637,6 +637,52 @@ __device__ __forceinline__ void inline_route(const RouteIO& rio, int my_e, int m
     __syncthreads();   // the lists are complete, and the mask area is free again
 }
 
+// The lists of a single token's k pairs, derived by ONE wave from registers: lane j < k holds the token's j-th pick
+// (global expert id).  An expert holds at most one pair, so a pair's place is the number of picked local experts with a
+// smaller id, and the tables are what inline_route() would leave.  Every wave of the workgroup calls this: all write the
+// same values to the same LDS words and each reads only behind its own writes, so no barrier is needed; wave 0 of
+// workgroup 0 also leaves the lists in the workspace for the launches that follow.
+__device__ __forceinline__ void single_token_route(const RouteIO& rio, int id_j, InlineTables* rt, int lane, int wave) {
+    const int k = rio.P;
+    const bool pair = lane < k;
+    const int e_j = id_j - rio.e_first;
+    const bool local = pair && e_j >= 0 && e_j < rio.E_local;
+    constexpr int OC = (INLINE_MAX_E + 1 + 63) / 64;
+    int pos = 0, off[OC];
+#pragma unroll
+    for (int c = 0; c < OC; c++) off[c] = 0;
+    for (int i = 0; i < k; i++) {
+        const int e_i = __builtin_amdgcn_readlane(e_j, i);
+        const bool local_i = __builtin_amdgcn_readlane((int)local, i) != 0;
+        pos += (local_i && e_i < e_j) ? 1 : 0;
+#pragma unroll
+        for (int c = 0; c < OC; c++) off[c] += (local_i && e_i < lane + 64 * c) ? 1 : 0;
+    }
+    const int n_local = __builtin_popcountll(__ballot(local));
+    const bool scribe = blockIdx.x == 0 && wave == 0;
+    if (local) {
+        rt->tile_e[pos] = e_j;
+        rt->tile_m0[pos] = 0;
+        rt->tok[pos] = lane;
+        if (scribe) { rio.tile_expert[pos] = e_j; rio.tile_m0[pos] = 0; rio.sorted[pos] = lane; rio.active[pos] = e_j; }
+    }
+#pragma unroll
+    for (int c = 0; c < OC; c++) {
+        const int e = lane + 64 * c;
+        if (e <= rio.E_local) {
+            rt->off[e] = off[c];
+            if (scribe) rio.offsets[e] = off[c];
+        }
+    }
+    if (lane == 0) {
+        rt->nt = n_local;
+        if (scribe) { *rio.n_active = n_local; *rio.n_tiles = n_local; }
+    }
+    if (scribe && pair) rio.inv[lane] = local ? pos : -1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // 256 x 32 code table with 256-byte rows: entry (byte, replica) = half2(code[byte & 15], code[byte >> 4]).  Thread t
 // writes replica t & 31 of the byte values whose low nibble is fixed by t >> 5, so its low code is chosen once (a select
 // chain over immediates) and the high code of each store is a compile-time constant: stores only, no reads, one barrier.
@@ -713,55 +759,19 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
             const int wv_ = (int)threadIdx.x >> 6, ln_ = (int)threadIdx.x & 63;
             constexpr int NW = PAIRS * KP;
             if (Tn == 1 && rio.r_E <= 64) {
-                // A single token (the whole batch of single-sequence decode): every wave picks AND buckets for itself, from
-                // registers, and leaves the same tables as inline_route() would -- an expert holds at most one pair, so a
-                // pair's place is the number of picked local experts with a smaller id.  All waves write the same values to
-                // the same LDS words and each reads only behind its own writes: no barrier in front of the first load.
+                // A single token (the whole batch of single-sequence decode): every wave picks AND buckets for itself
+                // (single_token_route): no barrier in front of the first load.
                 const float mine = ln_ < rio.r_E ? (float)rio.r_logits[ln_] : 0.f;
                 topk_softmax_wave64(mine, rio.r_E, rio.r_k, il, wl);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const bool pair = ln_ < rio.r_k;
                 const int id_j = pair ? il[ln_] : 0;
-                const int e_j = id_j - rio.e_first;
-                const bool local = pair && e_j >= 0 && e_j < rio.E_local;
-                int pos = 0, off[(INLINE_MAX_E + 1 + 63) / 64];
-#pragma unroll
-                for (int c = 0; c < (INLINE_MAX_E + 1 + 63) / 64; c++) off[c] = 0;
-                for (int i = 0; i < rio.r_k; i++) {
-                    const int e_i = __builtin_amdgcn_readlane(e_j, i);
-                    const bool local_i = __builtin_amdgcn_readlane((int)local, i) != 0;
-                    pos += (local_i && e_i < e_j) ? 1 : 0;
-#pragma unroll
-                    for (int c = 0; c < (INLINE_MAX_E + 1 + 63) / 64; c++) off[c] += (local_i && e_i < ln_ + 64 * c) ? 1 : 0;
-                }
-                const int n_local = __builtin_popcountll(__ballot(local));
-                const bool scribe = blockIdx.x == 0 && wv_ == 0;
-                if (local) {
-                    rt->tile_e[pos] = e_j;
-                    rt->tile_m0[pos] = 0;
-                    rt->tok[pos] = ln_;
-                    if (scribe) { rio.tile_expert[pos] = e_j; rio.tile_m0[pos] = 0; rio.sorted[pos] = ln_; rio.active[pos] = e_j; }
-                }
-#pragma unroll
-                for (int c = 0; c < (INLINE_MAX_E + 1 + 63) / 64; c++) {
-                    const int e = ln_ + 64 * c;
-                    if (e <= rio.E_local) {
-                        rt->off[e] = off[c];
-                        if (scribe) rio.offsets[e] = off[c];
-                    }
-                }
-                if (ln_ == 0) {
-                    rt->nt = n_local;
-                    if (scribe) { *rio.n_active = n_local; *rio.n_tiles = n_local; }
-                }
-                if (scribe && pair) {
-                    rio.inv[ln_] = local ? pos : -1;
+                single_token_route(rio, id_j, rt, ln_, wv_);
+                if (blockIdx.x == 0 && wv_ == 0 && pair) {
                     rio.ids_out[ln_] = id_j;
                     rio.w_out[ln_] = wl[ln_];
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
             } else {
             if (rio.r_E <= 64) {
                 constexpr int PER = 4;   // a wave's tokens four at a time, their logits requested together
@@ -802,12 +812,17 @@ __global__ __launch_bounds__(PAIRS * KP * 64) void moe_gemm_stream_kernel(
             // must have returned before any wave starts clearing
             __syncthreads();
             }
+        } else if (rio.P == k_top) {
+            // a single token with its picks given: every wave buckets them for itself, as above
+            const int ln_ = (int)threadIdx.x & 63;
+            single_token_route(rio, ln_ < k_top ? rio.ids[ln_] : 0, rt, ln_, (int)threadIdx.x >> 6);
         } else {
             if ((int)threadIdx.x < rio.P)
                 my_e = rio.ids[(int64_t)((int)threadIdx.x / k_top) * rio.ids_stride + (int)threadIdx.x % k_top] - rio.e_first;
         }
         if (my_e >= rio.E_local) my_e = -1;
-        if (!(INLINE == 2 && rio.P == rio.r_k && rio.r_E <= 64))   // (a single token has bucketed its pairs above)
+        // (a single token has bucketed its pairs above)
+        if (!(INLINE == 2 ? (rio.P == rio.r_k && rio.r_E <= 64) : rio.P == k_top))
             inline_route(rio, my_e, mt_rows, reinterpret_cast<uint32_t*>(red), rt, threadIdx.x, THREADS);
     } else {
         // The first 64 entries of the tile -> expert table are requested right away, one per lane, together with
