@@ -62,12 +62,18 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
     const int qi = lane & 31, hh = lane >> 5;
     const int qabs = q0 + qi;   // this lane's query (rows past the end compute on the last row and are not stored)
 
-    // Q fragments: B operand of step s holds Q[q][16 s + 8 h ..]
+    // Q fragments: B operand of step s holds Q[q][16 s + 8 h ..], scaled once by scale * log2(e) (rounded to fp16 again), so
+    // that the first product delivers the scores in the units of the exponent (exp2 below) and no per-score multiply is left
+    const float scale2 = scale * 1.44269504088896341f;
     half8_t qf[4];
     {
         const half_t* qrow = q + (int64_t)(s0 + min(qabs, L - 1)) * q_stride + (int64_t)hq * AP_D + 8 * hh;
 #pragma unroll
-        for (int s = 0; s < 4; s++) qf[s] = *reinterpret_cast<const half8_t*>(qrow + 16 * s);
+        for (int s = 0; s < 4; s++) {
+            const half8_t v = *reinterpret_cast<const half8_t*>(qrow + 16 * s);
+#pragma unroll
+            for (int j = 0; j < 8; j++) qf[s][j] = (half_t)((float)v[j] * scale2);
+        }
     }
     // keys this block of queries can see: up to its last query; from the window's start of its first query
     const int k_hi = min(q0 + AP_QBLK, L);                              // exclusive
@@ -98,8 +104,12 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
     const uint32_t voff = AP_TILE_BYTES + (4 * hh + ga) * 128 + (16 * dg + 4 * gc) * 2;
     const uint32_t vswz = (uint32_t)(((ga >> 1) & 1) * 64);   // which 64-byte half holds columns 0..31 of this lane's row
 
-    const float scale2 = scale * 1.44269504088896341f;
-    float m_run = -INFINITY, l_run = 0.f;   // running maximum (log2 units) and denominator of this lane's query
+    float m_run = -INFINITY, l_run = 0.f;   // reference point of the exponents (log2 units) and denominator of this lane's query
+    // minus the reference point in every element: the accumulator the first product starts from, so it delivers
+    // score - reference and the exponent needs no subtraction either (rewritten only when the reference moves)
+    float16_t nref;
+#pragma unroll
+    for (int i = 0; i < 16; i++) nref[i] = 0.f;
     float16_t o[2];
 #pragma unroll
     for (int i = 0; i < 16; i++) { o[0][i] = 0.f; o[1][i] = 0.f; }
@@ -115,17 +125,13 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
         for (int sub = 0; sub < 2; sub++) {
             const int kbase = t * AP_KVBLK + sub * 32;
             if (kbase >= k_hi) break;   // (uniform) nothing of this half tile is visible
-            float16_t x;
-#pragma unroll
-            for (int i = 0; i < 16; i++) x[i] = 0.f;
+            float16_t x = nref;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const half8_t a = *reinterpret_cast<ap_lds_h8_t*>(base + sub * 4096 + koff[s]);
                 x = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[s], x, 0, 0, 0);
             }
-            // register i of lane (q, h) is key kbase + (i & 3) + 8 (i >> 2) + 4 h
-            // The scores stay unscaled: the maximum is taken on the raw values (the scale is positive) and the scale
-            // (in units of log2(e): exp2 below) goes into the one fused multiply-add that forms the exponent.
+            // register i of lane (q, h) is key kbase + (i & 3) + 8 (i >> 2) + 4 h; x = score (log2 units) - reference.
             // only half tiles on the diagonal or on the window's edge need the per-element test
             const bool edge = kbase + 31 > q0 || (window > 0 && kbase <= q0 + AP_QBLK - 1 - window);
             if (edge) {
@@ -140,22 +146,32 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
 #pragma unroll
             for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, x[i]), x[i + 1]);
             mx = fmaxf(mx, x[15]);
-            mx = cross_half_max(mx) * scale2;
-            // The reference point of the exponents follows the running maximum lazily: it moves only when the maximum has
-            // grown by more than AP_LAZY (log2 units) beyond it, so the probabilities are at most 2^AP_LAZY instead of 1
-            // (fp16 holds them; the denominator carries the same factor) and the accumulator is rescaled a few times per
-            // query instead of whenever any of the 32 queries sees a new maximum.
-            const float m_top = fmaxf(m_run, mx);
-            const bool move = m_top > m_run + AP_LAZY;          // (-inf + AP_LAZY = -inf: the first visible key moves it)
-            const float m_new = move ? m_top : m_run;
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;   // every key so far masked: all terms are 0
-            const float alpha = move ? __builtin_amdgcn_exp2f(m_run - m_use) : 1.0f;
+            mx = cross_half_max(mx);   // how far the largest score of this half tile lies above the reference
+            // The reference point follows the running maximum lazily: it moves only when a score exceeds it by more than
+            // AP_LAZY (log2 units), so the probabilities are at most 2^AP_LAZY instead of 1 (fp16 holds them; the
+            // denominator carries the same factor) and the accumulator is rescaled a few times per query instead of
+            // whenever any of the 32 queries sees a new maximum.  Until a query has seen a key its reference is 0 and the
+            // first visible key moves it.
+            const bool first = m_run == -INFINITY;
+            const bool move = first ? mx > -INFINITY : mx > AP_LAZY;
+            const float delta = move ? mx : 0.f;
+            const float alpha = move ? (first ? 0.f : __builtin_amdgcn_exp2f(-delta)) : 1.0f;
+            if (__any(move)) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) x[i] -= delta;
+                m_run = move ? (first ? mx : m_run + mx) : m_run;
+                const float nr = (m_run == -INFINITY) ? 0.f : -m_run;
+#pragma unroll
+                for (int i = 0; i < 16; i++) nref[i] = nr;
+#pragma unroll
+                for (int i = 0; i < 16; i++) { o[0][i] *= alpha; o[1][i] *= alpha; }
+            }
             float rs = 0.f;
             half8_t pf[2];
 #pragma unroll
             for (int i = 0; i < 16; i += 2) {
-                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i], scale2, -m_use));
-                const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(x[i + 1], scale2, -m_use));
+                const float p0 = __builtin_amdgcn_exp2f(x[i]);
+                const float p1 = __builtin_amdgcn_exp2f(x[i + 1]);
                 const half2_t ph = {(half_t)p0, (half_t)p1};
                 pf[i >> 3][i & 7] = ph[0];
                 pf[i >> 3][(i & 7) + 1] = ph[1];
@@ -164,11 +180,6 @@ __global__ __launch_bounds__(AP_THREADS) void attn_prefill_kernel(
             }
             rs = cross_half_sum(rs);
             l_run = l_run * alpha + rs;
-            m_run = m_new;
-            if (__any(move)) {
-#pragma unroll
-                for (int i = 0; i < 16; i++) { o[0][i] *= alpha; o[1][i] *= alpha; }
-            }
             // O^T[d][q] += V^T[d][key] P^T[key][q]: element j of step s2 is key 16 s2 + 8 (j >> 2) + 4 h + (j & 3)
 #pragma unroll
             for (int dt = 0; dt < 2; dt++)
